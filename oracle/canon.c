@@ -1,0 +1,261 @@
+/* TEST INFRASTRUCTURE: canonical-arithmetic CPU oracle for the decode hot path.
+ *
+ * Only tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py may load the library
+ * built from this file; the product never does.
+ *
+ * What it restates: the per-step arithmetic behind the decode loop of
+ * /root/reference/src/inference.py:122-149 (model forward -> last-position logits -> argmax) for the
+ * model contracts used at its call sites (/root/reference/src/trainers/transformer_mt_trainer.py:91-98,
+ * /root/reference/src/trainers/cyclegan_trainer.py:329-332).  The model sources themselves are an absent
+ * submodule (/root/reference/.gitmodules:1-3), so the arithmetic follows the specification in
+ * oracle/torch_ref.py, against which this file is pinned (tests/test_oracle_golden.py).
+ *
+ * "Canonical arithmetic": every fp32 operation and every summation order is fixed, so that a second
+ * implementation that follows the same order (the HIP kernels) can be compared bit for bit.
+ *   - dot products of a GEMM: acc = bias[n] (or 0); for k ascending: acc = fmaf(a[m][k], w[k][n], acc)
+ *   - exp / log / sigmoid / tanh: the polynomial forms below (only +, *, fma, /, rint, bit operations)
+ *   - row sums over NL interleaved partial sums followed by an xor-butterfly (see sum_butterfly)
+ * Build: gcc -O3 -fPIC -shared -ffp-contract=off -mavx2 -mfma -fopenmp (no fast-math).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ scalar functions */
+static inline float as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+static inline uint32_t as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+float orc_exp(float x) {
+    if (!(x >= -87.0f)) return 0.0f; /* also maps -inf and NaN to 0 */
+    if (x > 88.0f) x = 88.0f;
+    float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = fmaf(p, r2, r) + 1.0f;
+    return y * as_float((uint32_t)((int)n + 127) << 23);
+}
+
+/* natural log for finite x > 0 (normal range) */
+float orc_log(float x) {
+    uint32_t u = as_uint(x);
+    int e = (int)((u >> 23) & 0xffu) - 127;
+    float m = as_float((u & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356237f) { m = m * 0.5f; e += 1; }
+    float f = m - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float p = 0.111111111111f;
+    p = fmaf(p, z, 0.142857142857f);
+    p = fmaf(p, z, 0.2f);
+    p = fmaf(p, z, 0.333333333333f);
+    p = p * z;
+    float s2 = s + s;
+    float r = fmaf(s2, p, s2);
+    float fe = (float)e;
+    r = fmaf(fe, 1.42860682030941723212e-6f, r);
+    return fmaf(fe, 0.693145751953125f, r);
+}
+
+float orc_sigmoid(float x) {
+    if (x >= 0.0f) { float e = orc_exp(-x); return 1.0f / (1.0f + e); }
+    float e = orc_exp(x);
+    return e / (1.0f + e);
+}
+
+float orc_tanh(float x) {
+    float a = fabsf(x);
+    float t = orc_exp(-2.0f * a);
+    float r = (1.0f - t) / (1.0f + t);
+    return copysignf(r, x);
+}
+
+void orc_map(int which, const float* x, float* y, int64_t n) {
+    for (int64_t i = 0; i < n; ++i)
+        y[i] = which == 0 ? orc_exp(x[i]) : which == 1 ? orc_log(x[i]) : which == 2 ? orc_sigmoid(x[i]) : orc_tanh(x[i]);
+}
+
+/* partial sums p[0..nl) -> total; nl a power of two <= 256.
+ * Within each aligned group of 64 partials: for off = 32,16,...,1 every p[l] becomes p[l] + p[l ^ off]
+ * (offsets >= the group size are skipped); groups of 64 are then added left to right. */
+static float sum_butterfly(float* p, int nl) {
+    int g = nl < 64 ? nl : 64;
+    float tmp[256];
+    for (int off = g >> 1; off >= 1; off >>= 1) {
+        for (int l = 0; l < nl; ++l) tmp[l] = p[l] + p[l ^ off];
+        memcpy(p, tmp, sizeof(float) * (size_t)nl);
+    }
+    float t = p[0];
+    for (int q = 64; q < nl; q += 64) t = t + p[q];
+    return t;
+}
+
+/* ------------------------------------------------------------------ GEMM */
+/* C[m][n] = epilogue( bias[n] + sum_k A[m][k] * Wt[k][n] ), k ascending, one fma per term.
+ * epilogue: relu if act == 1; then + res[m][n] if res != NULL. */
+void orc_gemm(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res,
+              int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act) {
+    enum { NB = 64 };
+    int64_t nchunks = (N + NB - 1) / NB;
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t c = 0; c < nchunks; ++c) {
+        int64_t n0 = c * NB;
+        int nb = (int)((N - n0) < NB ? (N - n0) : NB);
+        for (int64_t m = 0; m < M; ++m) {
+            float acc[NB];
+            for (int j = 0; j < NB; ++j) acc[j] = (bias && j < nb) ? bias[n0 + j] : 0.0f;
+            const float* a = A + m * lda;
+            if (nb == NB) {
+                for (int64_t k = 0; k < K; ++k) {
+                    float av = a[k];
+                    const float* w = Wt + k * ldw + n0;
+                    for (int j = 0; j < NB; ++j) acc[j] = fmaf(av, w[j], acc[j]);
+                }
+            } else {
+                for (int64_t k = 0; k < K; ++k) {
+                    float av = a[k];
+                    const float* w = Wt + k * ldw + n0;
+                    for (int j = 0; j < nb; ++j) acc[j] = fmaf(av, w[j], acc[j]);
+                }
+            }
+            for (int j = 0; j < nb; ++j) {
+                float v = acc[j];
+                if (act == 1) v = v > 0.0f ? v : 0.0f;
+                if (res) v = v + res[m * ldr + n0 + j];
+                C[m * ldc + n0 + j] = v;
+            }
+        }
+    }
+}
+
+/* ------------------------------------------------------------------ embedding + position */
+/* out[r][c] = emb[tok[r]][c] * scale + pe[c] (two roundings) */
+void orc_embed_posadd(const int32_t* tok, const float* emb, const float* pe, float scale, float* out, int64_t R,
+                      int64_t d) {
+    for (int64_t r = 0; r < R; ++r)
+        for (int64_t c = 0; c < d; ++c) {
+            float v = emb[(int64_t)tok[r] * d + c] * scale;
+            out[r * d + c] = pe ? v + pe[c] : v;
+        }
+}
+
+/* ------------------------------------------------------------------ LayerNorm */
+/* 64 interleaved partial sums (element c -> partial (c / 4) % 64, c ascending) + butterfly; biased variance. */
+void orc_layernorm(const float* x, const float* g, const float* b, float eps, float* y, int64_t R, int64_t d) {
+#pragma omp parallel for
+    for (int64_t r = 0; r < R; ++r) {
+        const float* xr = x + r * d;
+        float p[64];
+        for (int l = 0; l < 64; ++l) p[l] = 0.0f;
+        for (int64_t c = 0; c < d; ++c) p[(c >> 2) & 63] = p[(c >> 2) & 63] + xr[c];
+        float mean = sum_butterfly(p, 64) / (float)d;
+        for (int l = 0; l < 64; ++l) p[l] = 0.0f;
+        for (int64_t c = 0; c < d; ++c) { float dv = xr[c] - mean; p[(c >> 2) & 63] = fmaf(dv, dv, p[(c >> 2) & 63]); }
+        float var = sum_butterfly(p, 64) / (float)d;
+        float rstd = 1.0f / sqrtf(var + eps);
+        for (int64_t c = 0; c < d; ++c) y[r * d + c] = fmaf((xr[c] - mean) * rstd, g[c], b[c]);
+    }
+}
+
+/* ------------------------------------------------------------------ attention, one query per row */
+/* dot product over dh elements with 16 partial sums: element e -> partial (e / 4) % 16, e ascending,
+ * fma accumulation from 0; butterfly over the 16 partials. */
+static float dot16(const float* a, const float* b, int64_t dh) {
+    float p[16];
+    for (int l = 0; l < 16; ++l) p[l] = 0.0f;
+    for (int64_t e = 0; e < dh; ++e) { int l = (int)((e >> 2) & 15); p[l] = fmaf(a[e], b[e], p[l]); }
+    return sum_butterfly(p, 16);
+}
+
+/* q, out: [R][heads*dh].  K, V: [n_entries][n_stride][heads*dh]; row r attends to entry kv_row[r],
+ * positions 0..n-1; mask (optional) [n_entries][n_stride] bytes, 0 = position excluded.
+ * scores s_p = dot16(q, K_p) * scale; w_p = exp(s_p - max) / sum (64 interleaved partials + butterfly);
+ * out[c] = sum_p fma(w_p, V_p[c], acc), p ascending. */
+void orc_attention(const float* q, const float* K, const float* V, const int32_t* kv_row, const uint8_t* mask,
+                   int64_t R, int64_t n, int64_t n_stride, int64_t heads, int64_t dh, float scale, float* out) {
+    int64_t d = heads * dh;
+#pragma omp parallel for
+    for (int64_t r = 0; r < R; ++r) {
+        int64_t ent = kv_row ? kv_row[r] : r;
+        float* s = (float*)malloc(sizeof(float) * (size_t)n);
+        for (int64_t h = 0; h < heads; ++h) {
+            const float* qh = q + r * d + h * dh;
+            float mx = -INFINITY;
+            for (int64_t p = 0; p < n; ++p) {
+                if (mask && !mask[ent * n_stride + p]) { s[p] = -INFINITY; continue; }
+                s[p] = dot16(qh, K + (ent * n_stride + p) * d + h * dh, dh) * scale;
+                if (s[p] > mx) mx = s[p];
+            }
+            float part[64];
+            for (int l = 0; l < 64; ++l) part[l] = 0.0f;
+            for (int64_t p = 0; p < n; ++p) { s[p] = orc_exp(s[p] - mx); part[p & 63] = part[p & 63] + s[p]; }
+            float sum = sum_butterfly(part, 64);
+            for (int64_t p = 0; p < n; ++p) s[p] = s[p] / sum;
+            for (int64_t c = 0; c < dh; ++c) {
+                float acc = 0.0f;
+                for (int64_t p = 0; p < n; ++p)
+                    acc = fmaf(s[p], V[(ent * n_stride + p) * d + h * dh + c], acc);
+                out[r * d + h * dh + c] = acc;
+            }
+        }
+        free(s);
+    }
+}
+
+/* ------------------------------------------------------------------ GRU cell (PyTorch gate order r,z,n) */
+/* gi = x W_ih^T + b_ih, gh = h W_hh^T + b_hh, both [R][3H] */
+void orc_gru_cell(const float* gi, const float* gh, const float* h, float* hout, int64_t R, int64_t H) {
+    for (int64_t r = 0; r < R; ++r)
+        for (int64_t c = 0; c < H; ++c) {
+            const float* a = gi + r * 3 * H;
+            const float* b = gh + r * 3 * H;
+            float rg = orc_sigmoid(a[c] + b[c]);
+            float zg = orc_sigmoid(a[H + c] + b[H + c]);
+            float ng = orc_tanh(fmaf(rg, b[2 * H + c], a[2 * H + c]));
+            hout[r * H + c] = fmaf(zg, h[r * H + c], (1.0f - zg) * ng);
+        }
+}
+
+/* ------------------------------------------------------------------ selection over the vocabulary */
+/* first maximal index, the tie rule of torch.max used at /root/reference/src/inference.py:145 */
+void orc_argmax_rows(const float* x, int64_t ld, int64_t R, int64_t V, int32_t* out) {
+    for (int64_t r = 0; r < R; ++r) {
+        const float* xr = x + r * ld;
+        int64_t best = 0;
+        for (int64_t v = 1; v < V; ++v) if (xr[v] > xr[best]) best = v;
+        out[r] = (int32_t)best;
+    }
+}
+
+/* per row: lse = max + log(sum exp(x - max)) with 256 partial sums (element v -> partial (v / 4) % 256,
+ * v ascending) + butterfly; and the k largest logits (value desc, index asc). */
+void orc_logsoftmax_topk(const float* x, int64_t ld, int64_t R, int64_t V, int k, float* top_val, int32_t* top_idx,
+                         float* lse) {
+#pragma omp parallel for
+    for (int64_t r = 0; r < R; ++r) {
+        const float* xr = x + r * ld;
+        float mx = xr[0];
+        for (int64_t v = 1; v < V; ++v) if (xr[v] > mx) mx = xr[v];
+        float p[256];
+        for (int l = 0; l < 256; ++l) p[l] = 0.0f;
+        for (int64_t v = 0; v < V; ++v) { int l = (int)((v >> 2) & 255); p[l] = p[l] + orc_exp(xr[v] - mx); }
+        lse[r] = mx + orc_log(sum_butterfly(p, 256));
+        for (int j = 0; j < k; ++j) { top_val[r * k + j] = -INFINITY; top_idx[r * k + j] = -1; }
+        for (int64_t v = 0; v < V; ++v) {
+            float xv = xr[v];
+            int j = k;
+            while (j > 0 && xv > top_val[r * k + j - 1]) --j; /* strict: equal values keep the earlier index first */
+            if (j < k) {
+                for (int i = k - 1; i > j; --i) { top_val[r * k + i] = top_val[r * k + i - 1]; top_idx[r * k + i] = top_idx[r * k + i - 1]; }
+                top_val[r * k + j] = xv; top_idx[r * k + j] = (int32_t)v;
+            }
+        }
+    }
+}

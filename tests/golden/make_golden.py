@@ -1,0 +1,204 @@
+"""Generates the golden fixtures in this directory.  Run in the build container only:
+
+    python tests/golden/make_golden.py
+
+It imports the REAL decode loop, ``/root/reference/src/inference.py`` (``InferenceState``,
+``simple_inference``), and drives it with the model specifications of ``oracle/torch_ref.py`` on CPU in
+fp32.  The reference file needs ``firelab.utils.training_utils.cudable`` (a "move to GPU if there is
+one" helper, ``/root/reference/src/inference.py:5``), a third-party package that is not installed; an
+in-memory module whose ``cudable`` is the identity (its CPU behaviour) stands in for it.  Nothing of
+the reference is copied: the fixtures hold inputs and outputs only.
+
+Each ``<case>.npz`` holds: ``config`` (JSON: model kind, sizes, seeds, decode keys), the input arrays
+(``encs``/``enc_mask`` or ``z``), the reference's output sequences (``tokens`` padded with -1,
+``lens``) and, for the first steps, the last-position logits the model returned to the reference loop
+(``logits_s<i>``) with the original batch positions of the rows of that step (``rows_s<i>``).
+
+Cases whose name starts with ``beam_`` are NOT outputs of the reference (it has no beam search:
+``/root/reference/README.md:27,30``); they are made by ``oracle.torch_ref.ref_beam_search``, the
+torch statement of this build's own beam specification, and pin only the canonical oracle.
+"""
+import json
+import os
+import sys
+import types
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+from oracle import torch_ref as R
+
+
+def import_reference():
+    firelab = types.ModuleType('firelab')
+    utils = types.ModuleType('firelab.utils')
+    tu = types.ModuleType('firelab.utils.training_utils')
+    tu.cudable = lambda x: x
+    firelab.utils, utils.training_utils = utils, tu
+    sys.modules.update({'firelab': firelab, 'firelab.utils': utils, 'firelab.utils.training_utils': tu})
+    sys.path.insert(0, '/root/reference')
+    from src.inference import InferenceState, simple_inference
+    return InferenceState, simple_inference
+
+
+class Recorder:
+    """Wraps a model callable and records the last-position logits of the first ``keep`` calls."""
+
+    def __init__(self, model, keep):
+        self.model, self.keep, self.logits = model, keep, []
+
+    def __call__(self, *a, **kw):
+        out = self.model(*a, **kw)
+        lg = out[0] if isinstance(out, tuple) else out
+        if len(self.logits) < self.keep:
+            self.logits.append(lg[:, -1].detach().clone().numpy())
+        return out
+
+
+def pack_tokens(seqs):
+    lens = np.array([len(s) for s in seqs], dtype=np.int32)
+    tok = np.full((len(seqs), int(lens.max())), -1, dtype=np.int32)
+    for i, s in enumerate(seqs):
+        tok[i, :len(s)] = np.asarray(s, dtype=np.int32)
+    return tok, lens
+
+
+def rows_per_step(seqs_tokens, eos_free_lens, n_steps):
+    """Original batch positions still active at the start of each step (a row leaves after the step
+    in which it emitted EOS, i.e. a sequence stored with length L was active for steps 0..L-1)."""
+    rows = []
+    for s in range(n_steps):
+        rows.append(np.array([i for i, L in enumerate(eos_free_lens) if L - 1 >= s], dtype=np.int32))
+    return rows
+
+
+def save(name, config, arrays, seqs, rec, finished_lens):
+    tok, lens = pack_tokens(seqs)
+    out = dict(arrays)
+    out['tokens'], out['lens'] = tok, lens
+    rows = rows_per_step(seqs, finished_lens, len(rec.logits))
+    for i, lg in enumerate(rec.logits):
+        assert lg.shape[0] == len(rows[i]), (name, i, lg.shape, len(rows[i]))
+        out['logits_s%d' % i] = lg.astype(np.float32)
+        out['rows_s%d' % i] = rows[i]
+    out['config'] = np.frombuffer(json.dumps(config).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('%-16s B=%d lens=%s' % (name, len(seqs), lens.tolist()))
+
+
+def finished_lens_of(seqs, max_len):
+    """Number of steps each row was active: len(seq) for rows that emitted EOS (stored BOS-led and
+    EOS-stripped, so len = steps), max_len for rows cut off (stored with 1 + max_len tokens)."""
+    return [min(len(s), max_len) if len(s) <= max_len else max_len for s in seqs]
+
+
+def transformer_case(InferenceState, name, V, B, S_max, max_len, eos_bias, out_scale, seed, through_encoder, keep=6):
+    rs = np.random.RandomState(seed)
+    vocab = R.synthetic_vocab(V)
+    hp = R.mt_hp()
+    model = R.synthetic_init(R.Transformer(hp, vocab, vocab), vocab.stoi['<eos>'], eos_bias, out_scale, seed=42)
+    lens = rs.randint(4, S_max + 1, size=B)
+    lens[0] = S_max
+    arrays = {}
+    if through_encoder:
+        src = np.full((B, S_max), vocab.stoi['<pad>'], dtype=np.int64)
+        for b in range(B):
+            src[b, :lens[b]] = rs.randint(4, V, size=lens[b])
+        with torch.no_grad():
+            encs, enc_mask = model.encoder(torch.from_numpy(src))
+        arrays['src'] = src.astype(np.int32)
+    else:
+        encs = torch.from_numpy(rs.standard_normal((B, S_max, hp.d_model)).astype(np.float32))
+        enc_mask = torch.from_numpy(np.arange(S_max)[None, :] < lens[:, None]).unsqueeze(1)
+    arrays['encs'] = encs.numpy()
+    arrays['enc_mask'] = enc_mask.numpy()
+    rec = Recorder(model.decoder, keep)
+    with torch.no_grad():
+        seqs = InferenceState({'model': rec, 'inputs': encs, 'enc_mask': enc_mask, 'vocab': vocab,
+                               'max_len': max_len}).inference()
+    seqs = [s.tolist() for s in seqs]
+    config = dict(kind='transformer', V=V, hp=dict(hp), weight_seed=42, eos_bias=eos_bias, out_scale=out_scale,
+                  max_len=max_len, data_seed=seed, through_encoder=through_encoder, source='reference src/inference.py')
+    save(name, config, arrays, seqs, rec, finished_lens_of(seqs, max_len))
+    return model, vocab, encs, enc_mask
+
+
+def beam_case(name, encs, enc_mask, beam, alpha, max_len, base_config):
+    vocab = R.synthetic_vocab(base_config['V'])
+    model = R.synthetic_init(R.Transformer(R.HP(base_config['hp']), vocab, vocab), vocab.stoi['<eos>'],
+                             base_config['eos_bias'], base_config['out_scale'], seed=base_config['weight_seed'])
+    dec = model.decoder
+
+    def step_fn(prefixes, alive):
+        idx = torch.tensor([s for s in alive for _ in range(beam)])
+        width = max(len(p) for p in prefixes)  # finished beams are shorter; their logits are unused
+        ys = torch.tensor([p + [1] * (width - len(p)) for p in prefixes], dtype=torch.long)
+        with torch.no_grad():
+            return dec(encs[idx], ys, enc_mask[idx])[:, -1]
+
+    res = R.ref_beam_search(step_fn, encs.shape[0], beam, max_len, vocab.stoi['<bos>'], vocab.stoi['<eos>'], alpha)
+    tok, lens = pack_tokens([r[0] for r in res])
+    cfg = dict(base_config, beam=beam, alpha=alpha, max_len=max_len, source='build-defined beam spec (torch)')
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), tokens=tok, lens=lens,
+                        scores=np.array([r[1] for r in res], dtype=np.float32),
+                        encs=encs.numpy(), enc_mask=enc_mask.numpy(),
+                        config=np.frombuffer(json.dumps(cfg).encode(), dtype=np.uint8))
+    print('%-16s B=%d lens=%s' % (name, len(res), lens.tolist()))
+
+
+def gru_case(simple_inference, InferenceState, name, E, H, V, B, max_len, eos_token, eos_bias, out_scale, seed, keep=6):
+    rs = np.random.RandomState(seed)
+    vocab = R.synthetic_vocab(V, extra=('|',))
+    model = R.synthetic_init(R.RNNDecoder(E, H, vocab), vocab.stoi[eos_token], eos_bias, out_scale, seed=42)
+    z = torch.from_numpy(rs.standard_normal((B, H)).astype(np.float32))
+    rec = Recorder(model, keep)
+    with torch.no_grad():
+        seqs = simple_inference(rec, z, vocab, max_len=max_len, eos_token=eos_token)
+    config = dict(kind='gru', V=V, E=E, H=H, weight_seed=42, eos_bias=eos_bias, out_scale=out_scale, max_len=max_len,
+                  eos_token=eos_token, data_seed=seed, source='reference src/inference.py simple_inference')
+    save(name, config, {'z': z.numpy()}, seqs, rec, finished_lens_of(seqs, max_len))
+
+
+def stateful_case(InferenceState, name, E, H, V, n_layers, B, max_len, eos_bias, out_scale, seed, keep=6):
+    """The call pattern of ``/root/reference/src/prod/dialog_model.py:108-120`` with greedy selection
+    (sampling there is random and has no fixed output)."""
+    rs = np.random.RandomState(seed)
+    vocab = R.synthetic_vocab(V, extra=('|',))
+    model = R.synthetic_init(R.RNNLM(E, H, vocab, n_layers), vocab.stoi['|'], eos_bias, out_scale, seed=42)
+    z = torch.from_numpy(rs.standard_normal((n_layers, B, H)).astype(np.float32))
+    rec = Recorder(model, keep)
+    with torch.no_grad():
+        seqs = InferenceState({'model': rec, 'inputs': z, 'vocab': vocab, 'max_len': max_len, 'bos_token': '|',
+                               'eos_token': '|', 'substitute_inputs': True, 'inputs_batch_dim': 1,
+                               'kwargs': {'return_z': True}}).inference()
+    seqs = [s.tolist() for s in seqs]
+    config = dict(kind='rnnlm_stateful', V=V, E=E, H=H, n_layers=n_layers, weight_seed=42, eos_bias=eos_bias,
+                  out_scale=out_scale, max_len=max_len, data_seed=seed, source='reference src/inference.py (stateful)')
+    save(name, config, {'z': z.numpy()}, seqs, rec, finished_lens_of(seqs, max_len))
+
+
+def main():
+    torch.set_num_threads(4)
+    InferenceState, simple_inference = import_reference()
+    m, v, e, mk = transformer_case(InferenceState, 'tfm_v64', V=64, B=6, S_max=12, max_len=16, eos_bias=1.5,
+                                   out_scale=2.0, seed=101, through_encoder=False)
+    base = dict(kind='transformer', V=64, hp=dict(R.mt_hp()), weight_seed=42, eos_bias=0.25, out_scale=2.0)
+    beam_case('beam_tfm_v64_k4', e, mk, beam=4, alpha=0.0, max_len=12, base_config=base)
+    beam_case('beam_tfm_v64_k3a', e, mk, beam=3, alpha=0.6, max_len=12, base_config=base)
+    transformer_case(InferenceState, 'tfm_v1000', V=1000, B=8, S_max=14, max_len=20, eos_bias=2.2,
+                     out_scale=2.0, seed=102, through_encoder=True)
+    gru_case(simple_inference, InferenceState, 'gru_h32', E=32, H=32, V=40, B=5, max_len=12, eos_token='<eos>',
+             eos_bias=1.0, out_scale=2.0, seed=103)
+    gru_case(simple_inference, InferenceState, 'gru_h1024', E=1024, H=1024, V=128, B=4, max_len=24, eos_token='|',
+             eos_bias=0.5, out_scale=2.0, seed=104)
+    stateful_case(InferenceState, 'rnnlm_stateful', E=48, H=64, V=50, n_layers=2, B=4, max_len=14, eos_bias=1.0,
+                  out_scale=2.0, seed=105)
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,48 @@
+"""Shared helpers of the test-suite: fixture loading and model reconstruction from fixture configs."""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def load_fixture(name):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'))
+    fx = {k: z[k] for k in z.files}
+    fx['config'] = json.loads(bytes(fx['config']).decode())
+    fx['seqs'] = [fx['tokens'][i, :n].tolist() for i, n in enumerate(fx['lens'])]
+    return fx
+
+
+def torch_model_for(cfg):
+    """Rebuilds the torch specification model a fixture was made with (weights are a pure function of
+    the config: ``oracle.torch_ref.synthetic_init``)."""
+    from oracle import torch_ref as R
+    kind = cfg['kind']
+    if kind == 'transformer':
+        vocab = R.synthetic_vocab(cfg['V'])
+        model = R.synthetic_init(R.Transformer(R.HP(cfg['hp']), vocab, vocab), vocab.stoi['<eos>'], cfg['eos_bias'],
+                                 cfg['out_scale'], seed=cfg['weight_seed'])
+        return model, vocab
+    vocab = R.synthetic_vocab(cfg['V'], extra=('|',))
+    if kind == 'gru':
+        model = R.RNNDecoder(cfg['E'], cfg['H'], vocab)
+        eos = vocab.stoi[cfg['eos_token']]
+    elif kind == 'rnnlm_stateful':
+        model = R.RNNLM(cfg['E'], cfg['H'], vocab, cfg['n_layers'])
+        eos = vocab.stoi['|']
+    else:
+        raise ValueError(kind)
+    return R.synthetic_init(model, eos, cfg['eos_bias'], cfg['out_scale'], seed=cfg['weight_seed']), vocab
+
+
+def logits_close(a, b, rtol=1e-4, atol=1e-5):
+    """The fp32 tolerance of this build: |a - b| <= rtol * |b| + atol, elementwise."""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    err = np.abs(a - b) - (rtol * np.abs(b) + atol)
+    return bool((err <= 0).all()), float(np.abs(a - b).max())

@@ -1,0 +1,153 @@
+// Probe: which fp32 device operations are bit-identical to a host restatement?
+//   1. v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32 accumulation vs a k-ordered host fmaf chain
+//   2. correctly rounded divide / sqrt
+//   3. a polynomial exp built only from fma / mul / add / rint
+// Build: hipcc --offload-arch=gfx950 -O2 -ffp-contract=off -mfma -o probe_exact probe_exact.hip
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <cstdint>
+#include <vector>
+
+#define CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(2); } } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// one wave: C[32][32] = bias[n] + sum_k A[m][k] * B[k][n]
+__global__ void k_mfma32(const float* A, const float* B, const float* bias, float* C, int K) {
+    int l = threadIdx.x;
+    f32x16 acc;
+    for (int r = 0; r < 16; ++r) acc[r] = bias[l & 31];
+    for (int k = 0; k < K; k += 2) {
+        float a = A[(l & 31) * K + k + (l >> 5)];
+        float b = B[(k + (l >> 5)) * 32 + (l & 31)];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        C[row * 32 + (l & 31)] = acc[r];
+    }
+}
+
+// one wave: C[16][16]
+__global__ void k_mfma16(const float* A, const float* B, const float* bias, float* C, int K) {
+    int l = threadIdx.x;
+    f32x4 acc;
+    for (int r = 0; r < 4; ++r) acc[r] = bias[l & 15];
+    for (int k = 0; k < K; k += 4) {
+        float a = A[(l & 15) * K + k + (l >> 4)];
+        float b = B[(k + (l >> 4)) * 16 + (l & 15)];
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    }
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r;
+        C[row * 16 + (l & 15)] = acc[r];
+    }
+}
+
+__host__ __device__ inline float canon_exp(float x) {
+    // exp(x) for x <= 0 mostly; clamps
+    if (x < -87.0f) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    float n = rintf(x * 1.44269504088896341f);
+    float r = fmaf(n, -0.693145751953125f, x);
+    r = fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = fmaf(p, r2, r) + 1.0f;
+    int e = (int)n;
+    union { float f; uint32_t u; } s;
+    s.u = (uint32_t)(e + 127) << 23;
+    return y * s.f;
+}
+
+__global__ void k_elem(const float* x, const float* y, float* o_div, float* o_rsq, float* o_exp, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    o_div[i] = x[i] / y[i];
+    o_rsq[i] = 1.0f / sqrtf(fabsf(y[i]) + 1e-5f);
+    o_exp[i] = canon_exp(-fabsf(x[i]) * 10.0f);
+}
+
+static float frand() { return (float)rand() / RAND_MAX * 2.0f - 1.0f; }
+
+int main() {
+    srand(7);
+    int bad_total = 0;
+    for (int K : {2, 64, 256, 1024}) {
+        std::vector<float> A(32 * K), B(K * 32), bias(32), C(32 * 32), R(32 * 32);
+        for (auto& v : A) v = frand();
+        for (auto& v : B) v = frand();
+        for (auto& v : bias) v = frand();
+        float *dA, *dB, *db, *dC;
+        CHECK(hipMalloc(&dA, A.size() * 4)); CHECK(hipMalloc(&dB, B.size() * 4));
+        CHECK(hipMalloc(&db, 32 * 4)); CHECK(hipMalloc(&dC, 32 * 32 * 4));
+        CHECK(hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(db, bias.data(), 32 * 4, hipMemcpyHostToDevice));
+        k_mfma32<<<1, 64>>>(dA, dB, db, dC, K);
+        CHECK(hipMemcpy(C.data(), dC, 32 * 32 * 4, hipMemcpyDeviceToHost));
+        int bad = 0;
+        for (int m = 0; m < 32; ++m) for (int n = 0; n < 32; ++n) {
+            float acc = bias[n];
+            for (int k = 0; k < K; ++k) acc = fmaf(A[m * K + k], B[k * 32 + n], acc);
+            if (memcmp(&acc, &C[m * 32 + n], 4)) ++bad;
+        }
+        printf("mfma32x32x2 K=%d mismatches=%d/1024\n", K, bad); bad_total += bad;
+        // 16x16x4 (uses first 16 rows / cols with its own layout: A[16][K], B[K][16])
+        if (K >= 4) {
+            std::vector<float> A2(16 * K), B2(K * 16), C2(256);
+            for (auto& v : A2) v = frand();
+            for (auto& v : B2) v = frand();
+            CHECK(hipMemcpy(dA, A2.data(), A2.size() * 4, hipMemcpyHostToDevice));
+            CHECK(hipMemcpy(dB, B2.data(), B2.size() * 4, hipMemcpyHostToDevice));
+            k_mfma16<<<1, 64>>>(dA, dB, db, dC, K);
+            CHECK(hipMemcpy(C2.data(), dC, 256 * 4, hipMemcpyDeviceToHost));
+            bad = 0;
+            for (int m = 0; m < 16; ++m) for (int n = 0; n < 16; ++n) {
+                float acc = bias[n];
+                for (int k = 0; k < K; ++k) acc = fmaf(A2[m * K + k], B2[k * 16 + n], acc);
+                if (memcmp(&acc, &C2[m * 16 + n], 4)) ++bad;
+            }
+            printf("mfma16x16x4 K=%d mismatches=%d/256\n", K, bad); bad_total += bad;
+        }
+        hipFree(dA); hipFree(dB); hipFree(db); hipFree(dC);
+    }
+    {
+        int n = 1 << 20;
+        std::vector<float> x(n), y(n), d(n), r(n), e(n);
+        for (int i = 0; i < n; ++i) { x[i] = frand() * 9.0f; y[i] = frand() * 3.0f + 1e-3f; }
+        float *dx, *dy, *dd, *dr, *de;
+        CHECK(hipMalloc(&dx, n * 4)); CHECK(hipMalloc(&dy, n * 4)); CHECK(hipMalloc(&dd, n * 4));
+        CHECK(hipMalloc(&dr, n * 4)); CHECK(hipMalloc(&de, n * 4));
+        CHECK(hipMemcpy(dx, x.data(), n * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(dy, y.data(), n * 4, hipMemcpyHostToDevice));
+        k_elem<<<n / 256, 256>>>(dx, dy, dd, dr, de, n);
+        CHECK(hipMemcpy(d.data(), dd, n * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(r.data(), dr, n * 4, hipMemcpyDeviceToHost));
+        CHECK(hipMemcpy(e.data(), de, n * 4, hipMemcpyDeviceToHost));
+        int bd = 0, br = 0, be = 0; double maxrel = 0;
+        for (int i = 0; i < n; ++i) {
+            float hd = x[i] / y[i];
+            float hr = 1.0f / sqrtf(fabsf(y[i]) + 1e-5f);
+            float he = canon_exp(-fabsf(x[i]) * 10.0f);
+            if (memcmp(&hd, &d[i], 4)) ++bd;
+            if (memcmp(&hr, &r[i], 4)) ++br;
+            if (memcmp(&he, &e[i], 4)) ++be;
+            double t = exp((double)(-fabsf(x[i]) * 10.0f));
+            if (t > 1e-30) { double rel = fabs(he - t) / t; if (rel > maxrel) maxrel = rel; }
+        }
+        printf("div mismatches=%d rsqrt mismatches=%d exp mismatches=%d (n=%d) exp maxrel vs double=%.3e\n", bd, br, be, n, maxrel);
+        bad_total += bd + br + be;
+    }
+    printf("PROBE %s\n", bad_total == 0 ? "ALL_EXACT" : "HAS_MISMATCH");
+    return 0;
+}
