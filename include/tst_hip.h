@@ -1,0 +1,128 @@
+/* C ABI of libtst_hip.so: the gfx950 kernels behind the batched decode loop.
+ *
+ * The reference has no native code and no FFI: its decode loop (/root/reference/src/inference.py:11-181)
+ * calls a PyTorch model once per generated token and picks tokens with torch ops.  Each entry point
+ * below replaces the torch op(s) named in its comment; the Python package binds them with ctypes.
+ *
+ * Conventions: plain C; every pointer is a device pointer owned by the caller unless marked "host";
+ * no allocation, no synchronisation and no global mutable state inside (one thread per stream is
+ * safe); sizes are int64_t; the last argument is the hipStream_t to launch on (passed as void*);
+ * return value 0 = launched, negative = error (see TST_ERR_*), never an exception.
+ * All floating point is fp32 with a fixed operation order ("canonical arithmetic"): a GEMM output is
+ * acc = bias[n]; for k ascending: acc = fma(a[m][k], w[k][n], acc); row reductions use interleaved
+ * partial sums combined by an xor-butterfly; exp/log/sigmoid/tanh are fixed polynomials.
+ */
+#ifndef TST_HIP_H
+#define TST_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TST_OK 0
+#define TST_ERR_ARG (-1)         /* null pointer, bad size or alignment */
+#define TST_ERR_LAUNCH (-2)      /* the HIP runtime refused the launch */
+#define TST_ERR_UNSUPPORTED (-3) /* shape outside what the kernel was built for */
+
+/* ABI version of this header (major * 100 + minor). */
+int tst_version(void);
+/* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
+const char* tst_last_error(void);
+
+/* x[r][:] = emb[tok[r]][:] * scale + pe[pos[r]][:]   (pos NULL: the single row pe[0..d); pe NULL: no add)
+ * replaces nn.Embedding lookup * sqrt(d_model) + positional rows at the first line of a model forward
+ * called from /root/reference/src/inference.py:132.  d % 4 == 0. */
+int tst_embed_posadd_f32(const int32_t* tok, const float* emb, const float* pe, const int32_t* pos, float scale, float* x,
+                         int64_t R, int64_t d, int64_t V, void* stream);
+
+/* y = LayerNorm(x) over the last dimension (biased variance), rows of d floats, d % 4 == 0. */
+int tst_layernorm_f32(const float* x, const float* gamma, const float* beta, float eps, float* y, int64_t R, int64_t d,
+                      void* stream);
+
+/* C[M][N] = epilogue(bias[n] + sum_k A[m][k] * Wt[k][n]) on the fp32 matrix cores
+ * (v_mfma_f32_32x32x2_f32), epilogue = relu if act == 1, then + res[m][n] if res != NULL (res may alias C).
+ * Wt is the nn.Linear weight transposed to [K][ldw]; replaces nn.Linear / the GRU gate products / the
+ * vocabulary projection.  Requirements: K % 4 == 0, lda % 4 == 0, ldw % 4 == 0, ldw >= N,
+ * 16-byte aligned A and Wt. */
+int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res,
+                      int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream);
+
+/* One decoder self-attention step with an incremental KV cache.
+ * cache: [n_pos][slab_rows][3*d] fp32, the fused q|k|v projection output of every past step; the rows of
+ * position `pos` (the current step) must already be written.  Row r attends to positions p = 0..pos,
+ * reading k/v of position p from cache row anc[r*anc_ld + p] (p < pos) or row r (p == pos).
+ * out[r][d] = softmax(q k^T / sqrt(d/heads)) v per head.  replaces the decoder self-attention of the
+ * model called at /root/reference/src/inference.py:132 (whole-prefix recompute there). */
+int tst_attn_self_step_f32(const float* cache, int64_t slab_rows, const int32_t* anc, int64_t anc_ld, int64_t pos,
+                           float* out, int64_t R, int64_t d, int64_t heads, void* stream);
+
+/* One decoder cross-attention step.  q [R][d]; kv [n_sent][S][2*d] (k | v of the encoder outputs);
+ * mask [n_sent][S] bytes (0 = padding, may be NULL); row r uses sentence sent[r]. */
+int tst_attn_cross_step_f32(const float* q, const float* kv, const uint8_t* mask, const int32_t* sent, int64_t S,
+                            float* out, int64_t R, int64_t d, int64_t heads, void* stream);
+
+/* GRU cell update (PyTorch gate order r, z, n); gi = x W_ih^T + b_ih and gh = h W_hh^T + b_hh are [R][3H]:
+ * r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) * n + z * h.
+ * replaces the elementwise part of nn.GRU.  h_out may alias h.  H % 4 == 0. */
+int tst_gru_cell_step_f32(const float* gi, const float* gh, const float* h, float* h_out, int64_t R, int64_t H,
+                          void* stream);
+
+/* dst[r][:] = src[idx[r]][:], rows of `width` floats (width % 4 == 0); carried GRU state on reorder. */
+int tst_gather_rows_f32(const float* src, const int32_t* idx, float* dst, int64_t R, int64_t width, void* stream);
+
+/* tok[r] = index of the first maximal element of logits[r][0..V): torch.max(dim=-1)[1] at
+ * /root/reference/src/inference.py:145. */
+int tst_argmax_rows_f32(const float* logits, int64_t ld, int64_t R, int64_t V, int32_t* tok, void* stream);
+
+/* Per row: lse[r] = log sum exp(logits[r]) and the k largest logits (value descending, index ascending),
+ * 1 <= k <= 8, k <= V.  Feeds tst_beam_merge (the reference has no beam search; build-defined). */
+int tst_logsoftmax_topk_f32(const float* logits, int64_t ld, int64_t R, int64_t V, int64_t k, float* top_val,
+                            int32_t* top_idx, float* lse, void* stream);
+
+/* Decode-loop state.  All arrays are device memory owned by the caller; "cur" arrays are read, "nxt"
+ * arrays are written (ping-pong).  Rows of one sentence are contiguous (k rows per sentence).
+ *   hist  [rows][T+1] int32  tokens so far, BOS first          anc [rows][T] int32  cache row per position
+ *   sent  [rows] int32       original sentence of the row      tok [rows] int32     last token
+ *   score [rows] fp32        sum of log-probabilities          fin [rows] int32     1 = hypothesis ended
+ *   nemit [rows] int32       emitted tokens, EOS included */
+typedef struct tst_rows {
+    int32_t* hist;
+    int32_t* anc;
+    int32_t* sent;
+    int32_t* tok;
+    float* score;
+    int32_t* fin;
+    int32_t* nemit;
+} tst_rows;
+
+/* Beam merge, one sentence per thread: every live beam offers its k best tokens with value
+ * score + (top_val - lse), a finished beam offers itself unchanged, at step 0 only beam 0 offers; the k
+ * best offers (ties: lower beam, then lower rank) become the new beams.  Writes, per new row slot:
+ * parent (row index before the merge), tok, score, fin, nemit into sel_*. */
+int tst_beam_merge(const tst_rows* cur, const float* top_val, const int32_t* top_idx, const float* lse, int64_t n_sent,
+                   int64_t k, int64_t step, int32_t eos, int32_t* sel_parent, int32_t* sel_tok, float* sel_score,
+                   int32_t* sel_fin, int32_t* sel_nemit, void* stream);
+
+/* Greedy counterpart of tst_beam_merge (k = 1): parent = row, tok = argmax token, fin = (tok == eos). */
+int tst_greedy_select(const int32_t* argmax_tok, int64_t n_rows, int32_t eos, int32_t* sel_parent, int32_t* sel_tok,
+                      float* sel_score, int32_t* sel_fin, int32_t* sel_nemit, const tst_rows* cur, void* stream);
+
+/* Retire finished sentences and compact the batch: /root/reference/src/inference.py:94-120 and :65-69.
+ * A sentence ends when all its k new beams are finished or when last_step != 0; its best beam
+ * (score / lp[nemit], ties: lower beam; lp = length-penalty table of T + 2 floats) is written to
+ * out_tok[sentence][0..T], out_len (BOS included, EOS stripped) and out_score.  Surviving sentences keep
+ * their order; their rows are gathered from `cur` through sel_parent into `nxt`, the new token is
+ * appended to hist and the parent row index to anc (skipped when cur->anc is NULL); row_parent[new row]
+ * = old row, for callers that carry further per-row state.  scratch_alive_pos: 2 * n_sent int32.
+ * n_alive (device, 1 int32) receives the number of surviving sentences.  Three launches on `stream`. */
+int tst_retire_compact(const tst_rows* cur, const tst_rows* nxt, const int32_t* sel_parent, const int32_t* sel_tok,
+                       const float* sel_score, const int32_t* sel_fin, const int32_t* sel_nemit, const float* lp,
+                       int64_t n_sent, int64_t k, int64_t step, int64_t T, int32_t eos, int last_step, int32_t* out_tok,
+                       int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent,
+                       int32_t* n_alive, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -232,6 +232,44 @@ class _TransformerSession:
         return m.out(layernorm(x, *m.ln))
 
 
+class CanonTransformerEncoder:
+    """Evaluation of ``oracle.torch_ref.TransformerEncoder`` with the canonical arithmetic."""
+
+    def __init__(self, torch_encoder, n_heads):
+        sd = torch_encoder.state_dict()
+        self.d = sd['embed.weight'].shape[1]
+        self.heads, self.pad_idx = n_heads, torch_encoder.pad_idx
+        self.emb, self.pe = _np(sd['embed.weight']), _np(sd['pe'])
+        self.scale = float(np.float32(math.sqrt(self.d)))
+        self.layers = []
+        i = 0
+        while 'layers.%d.ln1.weight' % i in sd:
+            p = 'layers.%d.' % i
+            L = {n: (_np(sd[p + n + '.weight']), _np(sd[p + n + '.bias'])) for n in ('ln1', 'ln2')}
+            for n in ('q', 'k', 'v', 'o'):
+                L[n] = _Lin(sd, p + 'attn.' + n)
+            L['w1'], L['w2'] = _Lin(sd, p + 'ff.w1'), _Lin(sd, p + 'ff.w2')
+            self.layers.append(L)
+            i += 1
+        self.ln = (_np(sd['ln.weight']), _np(sd['ln.bias']))
+
+    def __call__(self, src):
+        src = np.asarray(src)
+        B, S = src.shape
+        mask = (src != self.pad_idx)
+        x = np.concatenate([embed_posadd(src[:, s], self.emb, self.pe[s], self.scale)[:, None] for s in range(S)], 1)
+        x = x.reshape(B * S, self.d)
+        sent = np.repeat(np.arange(B, dtype=np.int32), S)
+        for L in self.layers:
+            h = layernorm(x, *L['ln1'])
+            k = L['k'](h).reshape(B, S, self.d)
+            v = L['v'](h).reshape(B, S, self.d)
+            a = attention(L['q'](h), k, v, sent, mask, S, self.heads)
+            x = L['o'](a, res=x)
+            x = L['w2'](L['w1'](layernorm(x, *L['ln2']), act=1), res=x)
+        return layernorm(x, *self.ln).reshape(B, S, self.d), mask[:, None, :]
+
+
 class CanonGRUDecoder:
     """Carried-state evaluation of ``oracle.torch_ref.RNNDecoder`` / ``RNNLM`` (n_layers GRU + Linear)."""
 

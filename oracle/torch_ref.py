@@ -238,13 +238,14 @@ class RNNEncoder(nn.Module):
 
 
 class RNNLM(nn.Module):
-    """Multi-layer GRU language model with carried state ``z [n_layers, B, H]``."""
+    """Multi-layer GRU language model with carried state ``z [n_layers, B, size]``; constructor as at
+    ``/root/reference/src/prod/dialog_model.py:49``: ``RNNLM(size, vocab, n_layers=...)``."""
 
-    def __init__(self, emb_size, hid_size, vocab, n_layers=1):
+    def __init__(self, size, vocab, n_layers=1):
         super().__init__()
-        self.embed = nn.Embedding(len(vocab), emb_size)
-        self.gru = nn.GRU(emb_size, hid_size, num_layers=n_layers, batch_first=True)
-        self.out = nn.Linear(hid_size, len(vocab))
+        self.embed = nn.Embedding(len(vocab), size)
+        self.gru = nn.GRU(size, size, num_layers=n_layers, batch_first=True)
+        self.out = nn.Linear(size, len(vocab))
 
     def forward(self, z, x, return_z=False):
         hid, z_new = self.gru(self.embed(x), z)

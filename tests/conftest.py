@@ -1,0 +1,15 @@
+import os
+import sys
+
+# Keep the CPU-side oracle and torch from oversubscribing the cores they share.
+os.environ.setdefault('OMP_NUM_THREADS', '4')
+os.environ.setdefault('OMP_WAIT_POLICY', 'PASSIVE')
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, 'tests')):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')

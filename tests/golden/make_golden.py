@@ -164,12 +164,12 @@ def gru_case(simple_inference, InferenceState, name, E, H, V, B, max_len, eos_to
     save(name, config, {'z': z.numpy()}, seqs, rec, finished_lens_of(seqs, max_len))
 
 
-def stateful_case(InferenceState, name, E, H, V, n_layers, B, max_len, eos_bias, out_scale, seed, keep=6):
+def stateful_case(InferenceState, name, H, V, n_layers, B, max_len, eos_bias, out_scale, seed, keep=6):
     """The call pattern of ``/root/reference/src/prod/dialog_model.py:108-120`` with greedy selection
     (sampling there is random and has no fixed output)."""
     rs = np.random.RandomState(seed)
     vocab = R.synthetic_vocab(V, extra=('|',))
-    model = R.synthetic_init(R.RNNLM(E, H, vocab, n_layers), vocab.stoi['|'], eos_bias, out_scale, seed=42)
+    model = R.synthetic_init(R.RNNLM(H, vocab, n_layers), vocab.stoi['|'], eos_bias, out_scale, seed=42)
     z = torch.from_numpy(rs.standard_normal((n_layers, B, H)).astype(np.float32))
     rec = Recorder(model, keep)
     with torch.no_grad():
@@ -177,7 +177,7 @@ def stateful_case(InferenceState, name, E, H, V, n_layers, B, max_len, eos_bias,
                                'eos_token': '|', 'substitute_inputs': True, 'inputs_batch_dim': 1,
                                'kwargs': {'return_z': True}}).inference()
     seqs = [s.tolist() for s in seqs]
-    config = dict(kind='rnnlm_stateful', V=V, E=E, H=H, n_layers=n_layers, weight_seed=42, eos_bias=eos_bias,
+    config = dict(kind='rnnlm_stateful', V=V, H=H, n_layers=n_layers, weight_seed=42, eos_bias=eos_bias,
                   out_scale=out_scale, max_len=max_len, data_seed=seed, source='reference src/inference.py (stateful)')
     save(name, config, {'z': z.numpy()}, seqs, rec, finished_lens_of(seqs, max_len))
 
@@ -196,7 +196,7 @@ def main():
              eos_bias=1.0, out_scale=2.0, seed=103)
     gru_case(simple_inference, InferenceState, 'gru_h1024', E=1024, H=1024, V=128, B=4, max_len=24, eos_token='|',
              eos_bias=0.5, out_scale=2.0, seed=104)
-    stateful_case(InferenceState, 'rnnlm_stateful', E=48, H=64, V=50, n_layers=2, B=4, max_len=14, eos_bias=1.0,
+    stateful_case(InferenceState, 'rnnlm_stateful', H=64, V=50, n_layers=2, B=4, max_len=14, eos_bias=1.0,
                   out_scale=2.0, seed=105)
 
 

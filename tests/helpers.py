@@ -34,7 +34,7 @@ def torch_model_for(cfg):
         model = R.RNNDecoder(cfg['E'], cfg['H'], vocab)
         eos = vocab.stoi[cfg['eos_token']]
     elif kind == 'rnnlm_stateful':
-        model = R.RNNLM(cfg['E'], cfg['H'], vocab, cfg['n_layers'])
+        model = R.RNNLM(cfg['H'], vocab, cfg['n_layers'])
         eos = vocab.stoi['|']
     else:
         raise ValueError(kind)

@@ -1,0 +1,226 @@
+"""GPU: the decode path end to end through ``InferenceState`` / ``simple_inference``.
+
+  - golden fixtures (outputs of the real reference loop): tokens identical, per-step logits within the
+    fp32 tolerance |a-b| <= 1e-4 |b| + 1e-5;
+  - the canonical oracle on the same inputs: tokens, scores and logits bit for bit, greedy and beam;
+  - properties: beam of one == greedy, outputs independent of batch composition, foreign model callables.
+"""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_fixture, logits_close, torch_model_for
+from oracle import canon as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def T():
+    import tst_amd
+    assert torch.cuda.is_available()
+    return tst_amd
+
+
+def native_models(T, cfg):
+    """torch specification model of a fixture + the HIP-backed model with the same weights."""
+    tmodel, _ = torch_model_for(cfg)
+    if cfg['kind'] == 'transformer':
+        vocab = T.Vocab.synthetic(cfg['V'])
+        model = T.Transformer(T.HP(cfg['hp']), vocab, vocab)
+        model.load_state_dict(tmodel.state_dict())
+        return tmodel, model, vocab
+    vocab = T.Vocab.synthetic(cfg['V'], extra=('|',))
+    model = T.RNNDecoder(cfg['E'], cfg['H'], vocab) if cfg['kind'] == 'gru' else T.RNNLM(cfg['H'], vocab, cfg['n_layers'])
+    model.load_state_dict(tmodel.state_dict())
+    return tmodel, model, vocab
+
+
+def seqs_of(out):
+    return [s.cpu().tolist() for s in out]
+
+
+def state_for(T, fx, model, vocab, **extra):
+    cfg = fx['config']
+    if cfg['kind'] == 'transformer':
+        d = {'model': model.decoder, 'inputs': torch.from_numpy(fx['encs']).cuda(),
+             'enc_mask': torch.from_numpy(fx['enc_mask']).cuda(), 'vocab': vocab, 'max_len': cfg['max_len']}
+    elif cfg['kind'] == 'gru':
+        d = {'model': model, 'inputs': torch.from_numpy(fx['z']).cuda(), 'vocab': vocab, 'max_len': cfg['max_len'],
+             'eos_token': cfg['eos_token']}
+    else:
+        d = {'model': model, 'inputs': torch.from_numpy(fx['z']).cuda(), 'vocab': vocab, 'max_len': cfg['max_len'],
+             'bos_token': '|', 'eos_token': '|', 'substitute_inputs': True, 'inputs_batch_dim': 1,
+             'kwargs': {'return_z': True}}
+    d.update(extra)
+    return T.InferenceState(d)
+
+
+def canon_session(fx, tmodel, beam):
+    cfg = fx['config']
+    if cfg['kind'] == 'transformer':
+        return C.CanonTransformerDecoder(tmodel.decoder, cfg['hp']['n_heads']).session(fx['encs'], fx['enc_mask'], beam, cfg['max_len'])
+    return C.CanonGRUDecoder(tmodel).session(fx['z'], beam)
+
+
+def ids(fx, vocab):
+    cfg = fx['config']
+    if cfg['kind'] == 'rnnlm_stateful':
+        return vocab.stoi['|'], vocab.stoi['|'], fx['z'].shape[1]
+    if cfg['kind'] == 'gru':
+        return vocab.stoi['<bos>'], vocab.stoi[cfg['eos_token']], fx['z'].shape[0]
+    return vocab.stoi['<bos>'], vocab.stoi['<eos>'], fx['encs'].shape[0]
+
+
+@pytest.mark.parametrize('name', ['tfm_v64', 'tfm_v1000', 'gru_h32', 'gru_h1024', 'rnnlm_stateful'])
+def test_greedy_fixture_tokens_and_logits(T, name):
+    fx = load_fixture(name)
+    tmodel, model, vocab = native_models(T, fx['config'])
+    st = state_for(T, fx, model, vocab)
+    out = st.inference(keep_logits=6)
+    assert seqs_of(out) == fx['seqs']                                  # identical to the real reference loop
+    assert all(o.dtype == torch.long and o.is_cuda for o in out)
+    bos, eos, B = ids(fx, vocab)
+    cs, cl, cr = C.greedy_decode(canon_session(fx, tmodel, 1), B, fx['config']['max_len'], bos, eos, 6)
+    assert cs == fx['seqs']
+    n_kept = sum(1 for k in fx if k.startswith('logits_s'))
+    for i in range(n_kept):
+        lg, sent, _ = st.loop.kept[i]
+        assert np.array_equal(sent.cpu().numpy(), fx['rows_s%d' % i])
+        assert np.array_equal(lg.cpu().numpy(), cl[i])                  # bit-exact vs the canonical oracle
+        ok, err = logits_close(lg.cpu().numpy(), fx['logits_s%d' % i])  # fp32 tolerance vs the reference run
+        assert ok, (name, i, err)
+
+
+def test_simple_inference_matches_fixture(T):
+    fx = load_fixture('gru_h1024')
+    _, model, vocab = native_models(T, fx['config'])
+    out = T.simple_inference(model, torch.from_numpy(fx['z']).cuda(), vocab, max_len=fx['config']['max_len'], eos_token='|')
+    assert out == fx['seqs'] and isinstance(out[0], list) and isinstance(out[0][0], int)
+
+
+@pytest.mark.parametrize('name', ['beam_tfm_v64_k4', 'beam_tfm_v64_k3a'])
+def test_beam_fixture(T, name):
+    fx = load_fixture(name)
+    cfg = fx['config']
+    tmodel, model, vocab = native_models(T, cfg)
+    st = state_for(T, fx, model, vocab, beam_size=cfg['beam'], length_penalty=cfg['alpha'])
+    out = st.inference()
+    assert seqs_of(out) == fx['seqs']
+    cs, cscore, _, _ = C.beam_decode(canon_session(fx, tmodel, cfg['beam']), fx['encs'].shape[0], cfg['beam'], cfg['max_len'],
+                                     2, 3, cfg['alpha'])
+    assert cs == fx['seqs']
+    assert np.array_equal(st.scores.cpu().numpy(), cscore)              # bit-exact scores
+
+
+def random_case(T, V, B, S, max_len, eos_bias, seed, hp=None):
+    from oracle import torch_ref as R
+    hp = hp or R.mt_hp()
+    tv = R.synthetic_vocab(V)
+    tmodel = R.synthetic_init(R.Transformer(R.HP(hp), tv, tv), 3, eos_bias, 2.0, seed=seed)
+    vocab = T.Vocab.synthetic(V)
+    model = T.Transformer(T.HP(hp), vocab, vocab)
+    model.load_state_dict(tmodel.state_dict())
+    r = np.random.RandomState(seed)
+    lens = r.randint(3, S + 1, size=B)
+    encs = r.standard_normal((B, S, hp['d_model'])).astype(np.float32)
+    mask = (np.arange(S)[None] < lens[:, None])[:, None, :]
+    return tmodel, model, vocab, encs, mask
+
+
+@pytest.mark.parametrize('beam,alpha', [(1, 0.0), (4, 0.0), (4, 0.7), (8, 0.0)])
+def test_random_batch_bit_exact_vs_oracle(T, beam, alpha):
+    """64 sentences, V=2048, ragged sources: tokens and scores identical to the canonical oracle; the
+    batch shrinks as sentences finish, so compaction and beam reordering are exercised."""
+    tmodel, model, vocab, encs, mask = random_case(T, 2048, 64, 20, 24, 2.0 if beam == 1 else 0.5, 7)
+    st = T.InferenceState({'model': model.decoder, 'inputs': torch.from_numpy(encs).cuda(), 'enc_mask': torch.from_numpy(mask).cuda(),
+                           'vocab': vocab, 'max_len': 24, 'beam_size': beam, 'length_penalty': alpha})
+    out = seqs_of(st.inference(keep_logits=3))
+    sess = C.CanonTransformerDecoder(tmodel.decoder, 2).session(encs, mask, beam, 24)
+    if beam == 1:
+        want, logs, _ = C.greedy_decode(sess, 64, 24, 2, 3, 3)
+    else:
+        want, scores, logs, _ = C.beam_decode(sess, 64, beam, 24, 2, 3, alpha, 3)
+        assert np.array_equal(st.scores.cpu().numpy(), scores)
+    assert out == want
+    lens = [len(s) for s in out]
+    assert min(lens) < 25 and len(set(lens)) > 3                         # ragged termination really happened
+    for i in range(3):
+        lg, _, fin = st.loop.kept[i]
+        live = fin.cpu().numpy() == 0
+        assert np.array_equal(lg.cpu().numpy()[live], logs[i][live])
+
+
+def test_beam_one_equals_greedy_and_batch_independence(T):
+    tmodel, model, vocab, encs, mask = random_case(T, 512, 48, 16, 20, 1.5, 11)
+    def run(idx, beam):
+        st = T.InferenceState({'model': model.decoder, 'inputs': torch.from_numpy(encs[idx]).cuda(),
+                               'enc_mask': torch.from_numpy(mask[idx]).cuda(), 'vocab': vocab, 'max_len': 20, 'beam_size': beam})
+        return seqs_of(st.inference())
+    full = run(np.arange(48), 1)
+    # the beam machinery with one beam picks the arg-max token: same sequences as the greedy path
+    tst = T.InferenceState({'model': model.decoder, 'inputs': torch.from_numpy(encs).cuda(), 'enc_mask': torch.from_numpy(mask).cuda(),
+                            'vocab': vocab, 'max_len': 20, 'beam_size': 1})
+    tst.loop = None
+    assert full == seqs_of(tst.inference())
+    # a sentence's output does not depend on which other sentences share its batch
+    perm = np.random.RandomState(0).permutation(48)
+    part = run(perm[:17], 1)
+    assert part == [full[i] for i in perm[:17]]
+    part4 = run(perm[:9], 4)
+    full4 = run(np.arange(48), 4)
+    assert part4 == [full4[i] for i in perm[:9]]
+
+
+def test_foreign_model_callable(T):
+    """Any callable with the reference's model protocol works: here the torch specification model on the
+    GPU, called once per step on the whole prefix like /root/reference/src/inference.py:132."""
+    fx = load_fixture('tfm_v64')
+    tmodel, model, vocab = native_models(T, fx['config'])
+    tdec = tmodel.decoder.cuda()
+    st = state_for(T, fx, model, vocab, model=tdec)
+    assert seqs_of(st.inference()) == fx['seqs']
+    fx = load_fixture('rnnlm_stateful')
+    tmodel, model, vocab = native_models(T, fx['config'])
+    st = state_for(T, fx, model, vocab, model=tmodel.cuda())
+    assert seqs_of(st.inference()) == fx['seqs']
+
+
+def test_whole_prefix_call_and_encoder(T):
+    """``decoder(encs, ys, enc_mask)`` (teacher forcing) and ``encoder(src)`` against the torch
+    specification within the fp32 tolerance, and the encoder bit for bit against the canonical oracle."""
+    fx = load_fixture('tfm_v1000')
+    cfg = fx['config']
+    tmodel, model, vocab = native_models(T, cfg)
+    src = torch.from_numpy(fx['src']).long()
+    encs, enc_mask = model.encoder(src.cuda())
+    assert np.array_equal(enc_mask.cpu().numpy(), fx['enc_mask'])
+    want, _ = C.CanonTransformerEncoder(tmodel.encoder, cfg['hp']['n_heads'])(fx['src'])
+    assert np.array_equal(encs.cpu().numpy(), want)
+    valid = fx['enc_mask'][:, 0, :]
+    ok, err = logits_close(encs.cpu().numpy()[valid], fx['encs'][valid])
+    assert ok, err
+    ys = torch.from_numpy(np.random.RandomState(1).randint(4, 1000, size=(8, 9))).long()
+    with torch.no_grad():
+        ref = tmodel.decoder(torch.from_numpy(fx['encs']), ys, torch.from_numpy(fx['enc_mask']))
+    got = model.decoder(torch.from_numpy(fx['encs']).cuda(), ys.cuda(), torch.from_numpy(fx['enc_mask']).cuda())
+    ok, err = logits_close(got.cpu().numpy(), ref.numpy())
+    assert ok, err
+    # end to end through the product's own encoder: same tokens as the reference fixture
+    st = T.InferenceState({'model': model.decoder, 'inputs': encs, 'enc_mask': enc_mask, 'vocab': vocab, 'max_len': cfg['max_len']})
+    assert seqs_of(st.inference()) == fx['seqs']
+
+
+def test_stack_finished_and_errors(T):
+    fx = load_fixture('gru_h32')
+    _, model, vocab = native_models(T, fx['config'])
+    st = state_for(T, fx, model, vocab, should_stack_finished=True)
+    out = st.inference()
+    width = max(len(s) for s in fx['seqs'])
+    assert tuple(out.shape) == (len(fx['seqs']), width)
+    for i, s in enumerate(fx['seqs']):
+        assert out[i, :len(s)].long().cpu().tolist() == s and (out[i, len(s):] == 1).all()
+    with pytest.raises(NotImplementedError):
+        state_for(T, fx, model, vocab, sample_type='nucleus').inference()
+    with pytest.raises(ValueError):
+        state_for(T, fx, model, vocab, beam_size=9).inference()

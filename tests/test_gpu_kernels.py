@@ -1,0 +1,190 @@
+"""GPU: every kernel, called through the C ABI, against the canonical oracle — bit for bit
+(``np.array_equal``; the canonical arithmetic fixes every fp32 operation and its order)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import canon as C
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def K():
+    import tst_amd
+    from tst_amd import kernels
+    assert torch.cuda.is_available()
+    return kernels
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def rs(seed):
+    return np.random.RandomState(seed)
+
+
+@pytest.mark.parametrize('M,N,K_,bias,act,res', [
+    (1, 4, 4, False, 0, False), (5, 50, 48, True, 0, False), (130, 200, 36, True, 1, False),
+    (300, 1000, 256, True, 0, True), (257, 128, 1024, True, 1, True), (64, 3072, 1024, True, 0, False),
+    (1000, 768, 256, True, 0, False), (129, 129, 20, False, 1, True)])
+def test_gemm_bit_exact(K, M, N, K_, bias, act, res):
+    r = rs(M * 7 + N)
+    A = r.standard_normal((M, K_)).astype(np.float32)
+    W = r.standard_normal((K_, N)).astype(np.float32)
+    b = r.standard_normal(N).astype(np.float32) if bias else None
+    R0 = r.standard_normal((M, N)).astype(np.float32) if res else None
+    ldw = (N + 3) // 4 * 4
+    Wd = torch.zeros((K_, ldw), dtype=torch.float32, device='cuda')
+    Wd[:, :N] = dev(W)
+    out = torch.full((M, ldw), 7.0, dtype=torch.float32, device='cuda')
+    K.gemm(dev(A), Wd[:, :N], None if b is None else dev(b), out, M, res=None if R0 is None else dev(R0), act=act)
+    want = C.gemm(A, W, b, R0, act)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, :N], want)
+    assert (got[:, N:] == 7.0).all()  # nothing written beyond column N
+
+
+def test_gemm_in_place_residual_and_row_prefix(K):
+    r = rs(3)
+    A = r.standard_normal((200, 64)).astype(np.float32)
+    W = r.standard_normal((64, 64)).astype(np.float32)
+    X = r.standard_normal((200, 64)).astype(np.float32)
+    x = dev(X)
+    K.gemm(dev(A), dev(W), None, x, 150, res=x)
+    got = x.cpu().numpy()
+    assert np.array_equal(got[:150], C.gemm(A[:150], W, None, X[:150]))
+    assert np.array_equal(got[150:], X[150:])
+
+
+@pytest.mark.parametrize('d', [32, 256, 512, 1000])
+def test_layernorm_bit_exact(K, d):
+    r = rs(d)
+    x = (r.standard_normal((37, d)) * 3 + 1).astype(np.float32)
+    g, b = r.standard_normal(d).astype(np.float32), r.standard_normal(d).astype(np.float32)
+    y = torch.empty((37, d), dtype=torch.float32, device='cuda')
+    K.layernorm(dev(x), dev(g), dev(b), y, 37)
+    assert np.array_equal(y.cpu().numpy(), C.layernorm(x, g, b))
+
+
+def test_embed_posadd_bit_exact(K):
+    r = rs(5)
+    emb = r.standard_normal((50, 64)).astype(np.float32)
+    pe = r.standard_normal((9, 64)).astype(np.float32)
+    tok = r.randint(0, 50, size=33).astype(np.int32)
+    out = torch.empty((33, 64), dtype=torch.float32, device='cuda')
+    K.embed_posadd(dev(tok), dev(emb), dev(pe[3]), 8.0, out, 33)
+    assert np.array_equal(out.cpu().numpy(), C.embed_posadd(tok, emb, pe[3], 8.0))
+    pos = r.randint(0, 9, size=33).astype(np.int32)
+    K.embed_posadd(dev(tok), dev(emb), dev(pe), 8.0, out, 33, pos=dev(pos))
+    want = np.stack([C.embed_posadd(tok[i:i + 1], emb, pe[pos[i]], 8.0)[0] for i in range(33)])
+    assert np.array_equal(out.cpu().numpy(), want)
+    K.embed_posadd(dev(tok), dev(emb), None, 1.0, out, 33)
+    assert np.array_equal(out.cpu().numpy(), emb[tok])
+
+
+@pytest.mark.parametrize('d,heads,pos', [(256, 2, 0), (256, 2, 7), (256, 2, 49), (512, 8, 20), (64, 2, 5), (96, 1, 70)])
+def test_attn_self_step_bit_exact(K, d, heads, pos):
+    r = rs(d + pos)
+    R, slab, T = 21, 32, pos + 3
+    cache = r.standard_normal((T, slab, 3 * d)).astype(np.float32)
+    anc = r.randint(0, slab, size=(R, T)).astype(np.int32)
+    out = torch.empty((R, d), dtype=torch.float32, device='cuda')
+    K.attn_self_step(dev(cache), dev(anc), pos, out, R, d, heads)
+    # oracle: gather each row's logical K/V sequence
+    slots = anc[:, :pos + 1].copy()
+    slots[:, pos] = np.arange(R)
+    Kc = np.stack([np.stack([cache[p, slots[i, p], d:2 * d] for p in range(pos + 1)]) for i in range(R)])
+    Vc = np.stack([np.stack([cache[p, slots[i, p], 2 * d:] for p in range(pos + 1)]) for i in range(R)])
+    q = np.stack([cache[pos, i, :d] for i in range(R)])
+    assert np.array_equal(out.cpu().numpy(), C.attention(q, Kc, Vc, None, None, pos + 1, heads))
+
+
+@pytest.mark.parametrize('d,heads,S,masked', [(256, 2, 12, True), (256, 2, 42, True), (512, 8, 9, False), (128, 1, 100, True)])
+def test_attn_cross_step_bit_exact(K, d, heads, S, masked):
+    r = rs(d + S)
+    B, R = 7, 26
+    q = r.standard_normal((R, d)).astype(np.float32)
+    kv = r.standard_normal((B, S, 2 * d)).astype(np.float32)
+    sent = r.randint(0, B, size=R).astype(np.int32)
+    lens = r.randint(1, S + 1, size=B)
+    mask = (np.arange(S)[None] < lens[:, None]).astype(np.uint8) if masked else None
+    out = torch.empty((R, d), dtype=torch.float32, device='cuda')
+    K.attn_cross_step(dev(q), dev(kv), None if mask is None else dev(mask), dev(sent), out, R, d, heads)
+    want = C.attention(q, kv[:, :, :d], kv[:, :, d:], sent, mask, S, heads)
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_gru_cell_bit_exact(K):
+    r = rs(11)
+    R, H = 19, 64
+    gi, gh = (r.standard_normal((R, 3 * H)) * 2).astype(np.float32), (r.standard_normal((R, 3 * H)) * 2).astype(np.float32)
+    h = r.standard_normal((R, H)).astype(np.float32)
+    hd = dev(h)
+    K.gru_cell_step(dev(gi), dev(gh), hd, hd, R)
+    assert np.array_equal(hd.cpu().numpy(), C.gru_cell(gi, gh, h))
+
+
+def test_gather_rows(K):
+    r = rs(12)
+    src = r.standard_normal((40, 32)).astype(np.float32)
+    idx = r.randint(0, 40, size=25).astype(np.int32)
+    dst = torch.zeros((25, 32), dtype=torch.float32, device='cuda')
+    K.gather_rows(dev(src), dev(idx), dst, 25)
+    assert np.array_equal(dst.cpu().numpy(), src[idx])
+
+
+@pytest.mark.parametrize('V', [5, 50, 1000, 32000, 40001])
+def test_argmax_rows_first_max(K, V):
+    r = rs(V)
+    x = r.standard_normal((13, V)).astype(np.float32)
+    x[1, :] = 0.5                      # all equal: index 0
+    x[2, [V - 1, V // 2]] = 9.0        # tie: the earlier index
+    x[3, V - 1] = 9.0                  # max in the last (possibly partial) chunk
+    ld = (V + 3) // 4 * 4
+    xd = torch.zeros((13, ld), dtype=torch.float32, device='cuda')
+    xd[:, :V] = dev(x)
+    tok = torch.empty(13, dtype=torch.int32, device='cuda')
+    K.argmax_rows(xd, 13, V, tok)
+    assert np.array_equal(tok.cpu().numpy(), C.argmax_rows(x))
+    assert np.array_equal(tok.cpu().numpy(), x.argmax(1))
+
+
+@pytest.mark.parametrize('V,k', [(8, 8), (50, 3), (1000, 4), (32000, 4), (32000, 8), (32000, 1), (40004, 5), (33001, 2)])
+def test_logsoftmax_topk_bit_exact(K, V, k):
+    r = rs(V + k)
+    R = 9
+    x = (r.standard_normal((R, V)) * 2).astype(np.float32)
+    x[1, :] = -1.25                                  # all equal: candidate list overflows -> whole-row rounds
+    x[2, r.randint(0, V, size=min(V, 3000))] = 4.0   # many ties at the top
+    x[3, V - 1] = 50.0
+    ld = (V + 3) // 4 * 4
+    xd = torch.zeros((R, ld), dtype=torch.float32, device='cuda')
+    xd[:, :V] = dev(x)
+    tv = torch.empty((R, k), dtype=torch.float32, device='cuda')
+    ti = torch.empty((R, k), dtype=torch.int32, device='cuda')
+    lse = torch.empty(R, dtype=torch.float32, device='cuda')
+    K.logsoftmax_topk(xd, R, V, k, tv, ti, lse)
+    wv, wi, wl = C.logsoftmax_topk(x, k)
+    assert np.array_equal(ti.cpu().numpy(), wi)
+    assert np.array_equal(tv.cpu().numpy(), wv)
+    assert np.array_equal(lse.cpu().numpy(), wl)
+    ref = torch.logsumexp(torch.from_numpy(x).double(), -1).numpy()
+    assert np.allclose(wl, ref, rtol=1e-6, atol=1e-6)
+
+
+def test_logsoftmax_topk_unaligned_rows(K):
+    r = rs(77)
+    V, R, k = 1001, 6, 4
+    x = r.standard_normal((R, V)).astype(np.float32)
+    xd = dev(x)  # ld = 1001: rows are not 16-byte aligned
+    tv = torch.empty((R, k), dtype=torch.float32, device='cuda')
+    ti = torch.empty((R, k), dtype=torch.int32, device='cuda')
+    lse = torch.empty(R, dtype=torch.float32, device='cuda')
+    K.logsoftmax_topk(xd, R, V, k, tv, ti, lse)
+    wv, wi, wl = C.logsoftmax_topk(x, k)
+    assert np.array_equal(ti.cpu().numpy(), wi) and np.array_equal(tv.cpu().numpy(), wv) and np.array_equal(lse.cpu().numpy(), wl)
+    tok = torch.empty(R, dtype=torch.int32, device='cuda')
+    K.argmax_rows(xd, R, V, tok)
+    assert np.array_equal(tok.cpu().numpy(), x.argmax(1))

@@ -1,0 +1,101 @@
+"""CPU: pins the oracle.  (1) The torch restatement of the reference decode loop and (2) the
+canonical-arithmetic C oracle must both reproduce the golden fixtures, which were produced by the real
+``/root/reference/src/inference.py`` (see tests/golden/make_golden.py): tokens exactly, per-step logits
+within the fp32 tolerance of this build (|a-b| <= 1e-4 |b| + 1e-5)."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import load_fixture, logits_close, torch_model_for
+from oracle import canon as C
+from oracle import torch_ref as R
+
+GREEDY = ['tfm_v64', 'tfm_v1000', 'gru_h32', 'gru_h1024', 'rnnlm_stateful']
+KEEP = 6
+
+
+def run_torch_restatement(fx, model, vocab):
+    cfg = fx['config']
+    if cfg['kind'] == 'transformer':
+        st = R.RefInferenceState({'model': model.decoder, 'inputs': torch.from_numpy(fx['encs']),
+                                  'enc_mask': torch.from_numpy(fx['enc_mask']), 'vocab': vocab, 'max_len': cfg['max_len']})
+    elif cfg['kind'] == 'gru':
+        st = R.RefInferenceState({'model': model, 'inputs': torch.from_numpy(fx['z']), 'vocab': vocab,
+                                  'max_len': cfg['max_len'], 'eos_token': cfg['eos_token']})
+    else:
+        st = R.RefInferenceState({'model': model, 'inputs': torch.from_numpy(fx['z']), 'vocab': vocab,
+                                  'max_len': cfg['max_len'], 'bos_token': '|', 'eos_token': '|', 'substitute_inputs': True,
+                                  'inputs_batch_dim': 1, 'kwargs': {'return_z': True}})
+    seqs = [s.tolist() for s in st.inference(keep_logits=KEEP)]
+    return seqs, [l.numpy() for l in st.step_logits], [r.numpy() for r in st.step_rows]
+
+
+def run_canon(fx, model, vocab):
+    cfg = fx['config']
+    if cfg['kind'] == 'transformer':
+        sess = C.CanonTransformerDecoder(model.decoder, cfg['hp']['n_heads']).session(fx['encs'], fx['enc_mask'], 1, cfg['max_len'])
+        return C.greedy_decode(sess, fx['encs'].shape[0], cfg['max_len'], vocab.stoi['<bos>'], vocab.stoi['<eos>'], KEEP)
+    sess = C.CanonGRUDecoder(model).session(fx['z'])
+    if cfg['kind'] == 'gru':
+        return C.greedy_decode(sess, fx['z'].shape[0], cfg['max_len'], vocab.stoi['<bos>'], vocab.stoi[cfg['eos_token']], KEEP)
+    return C.greedy_decode(sess, fx['z'].shape[1], cfg['max_len'], vocab.stoi['|'], vocab.stoi['|'], KEEP)
+
+
+@pytest.mark.parametrize('name', GREEDY)
+@pytest.mark.parametrize('which', ['torch_restatement', 'canonical_oracle'])
+def test_greedy_matches_reference_fixture(name, which):
+    fx = load_fixture(name)
+    model, vocab = torch_model_for(fx['config'])
+    seqs, logits, rows = (run_torch_restatement if which == 'torch_restatement' else run_canon)(fx, model, vocab)
+    assert seqs == fx['seqs']
+    n_kept = sum(1 for k in fx if k.startswith('logits_s'))
+    assert n_kept > 0 and len(logits) >= n_kept
+    for i in range(n_kept):
+        assert np.array_equal(rows[i], fx['rows_s%d' % i])
+        ok, err = logits_close(logits[i], fx['logits_s%d' % i])
+        assert ok, (name, which, i, err)
+
+
+@pytest.mark.parametrize('name', ['beam_tfm_v64_k4', 'beam_tfm_v64_k3a'])
+def test_canonical_beam_matches_torch_beam_fixture(name):
+    """Beam search is build-defined (the reference has none); the fixture comes from the torch statement
+    of the specification, the canonical oracle must agree with it."""
+    fx = load_fixture(name)
+    cfg = fx['config']
+    model, vocab = torch_model_for(cfg)
+    dec = C.CanonTransformerDecoder(model.decoder, cfg['hp']['n_heads'])
+    B = fx['encs'].shape[0]
+    seqs, scores, _, _ = C.beam_decode(dec.session(fx['encs'], fx['enc_mask'], cfg['beam'], cfg['max_len']), B, cfg['beam'],
+                                       cfg['max_len'], vocab.stoi['<bos>'], vocab.stoi['<eos>'], cfg['alpha'])
+    assert seqs == fx['seqs']
+    assert np.allclose(scores, fx['scores'], rtol=1e-5, atol=1e-4)
+
+
+def test_beam_of_one_is_greedy():
+    fx = load_fixture('tfm_v64')
+    cfg = fx['config']
+    model, vocab = torch_model_for(cfg)
+    dec = C.CanonTransformerDecoder(model.decoder, cfg['hp']['n_heads'])
+    B = fx['encs'].shape[0]
+    seqs, _, _, _ = C.beam_decode(dec.session(fx['encs'], fx['enc_mask'], 1, cfg['max_len']), B, 1, cfg['max_len'],
+                                  vocab.stoi['<bos>'], vocab.stoi['<eos>'], 0.0)
+    assert seqs == fx['seqs']
+
+
+def test_canonical_functions_close_to_libm():
+    x = np.linspace(-30, 30, 20001).astype(np.float32)
+    assert np.allclose(C.fmap(0, x), np.exp(x.astype(np.float64)), rtol=2e-7)
+    assert np.allclose(C.fmap(2, x), 1 / (1 + np.exp(-x.astype(np.float64))), rtol=4e-7, atol=1e-38)
+    assert np.allclose(C.fmap(3, x), np.tanh(x.astype(np.float64)), rtol=0, atol=2e-7)
+    y = np.exp(np.linspace(-20, 20, 20001)).astype(np.float32)
+    assert np.allclose(C.fmap(1, y), np.log(y.astype(np.float64)), rtol=3e-7, atol=2e-7)
+
+
+def test_canonical_encoder_close_to_torch():
+    fx = load_fixture('tfm_v1000')
+    model, vocab = torch_model_for(fx['config'])
+    encs, mask = C.CanonTransformerEncoder(model.encoder, fx['config']['hp']['n_heads'])(fx['src'])
+    assert np.array_equal(mask, fx['enc_mask'])
+    valid = fx['enc_mask'][:, 0, :]
+    ok, err = logits_close(encs[valid], fx['encs'][valid])
+    assert ok, err

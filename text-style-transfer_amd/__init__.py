@@ -1,0 +1,16 @@
+"""MI355X-native batched decoding (greedy / beam) for transformer and GRU encoder-decoders.
+
+Host side of ``libtst_hip.so``: the call surface of the reference's ``src/inference.py`` and of the model
+classes it drives, with all per-step arithmetic in hand-written gfx950 kernels.  Importing this package
+requires the built library (``csrc/build.sh``); there is no CPU or PyTorch fallback path.
+"""
+from . import _lib
+from ._lib import TstError, version
+from .vocab import Vocab
+from .inference import InferenceState, simple_inference
+from .transformer import HP, Transformer, TransformerDecoder
+from .encoder import TransformerEncoder
+from .rnn import RNNDecoder, RNNLM
+
+__all__ = ['InferenceState', 'simple_inference', 'Vocab', 'HP', 'Transformer', 'TransformerDecoder',
+           'TransformerEncoder', 'RNNDecoder', 'RNNLM', 'TstError', 'version']

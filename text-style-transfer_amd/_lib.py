@@ -1,0 +1,62 @@
+"""ctypes binding of ``libtst_hip.so`` (declared in ``include/tst_hip.h``).
+
+The library is built in-tree by ``csrc/build.sh`` (``__graft_entry__.build()``).  There is no fallback:
+if it is missing, importing this module raises, and every wrapper raises on a non-zero status.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libtst_hip.so')
+
+c_i64, c_i32, c_f32, c_vp, c_int = ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_int
+
+
+class TstRows(ctypes.Structure):
+    """``tst_rows`` of include/tst_hip.h"""
+    _fields_ = [(n, c_vp) for n in ('hist', 'anc', 'sent', 'tok', 'score', 'fin', 'nemit')]
+
+
+_PROTOS = {
+    'tst_version': ([], c_int),
+    'tst_last_error': ([], ctypes.c_char_p),
+    'tst_embed_posadd_f32': ([c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
+    'tst_layernorm_f32': ([c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_vp], c_int),
+    'tst_gemm_mfma_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp], c_int),
+    'tst_attn_self_step_f32': ([c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
+    'tst_attn_cross_step_f32': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
+    'tst_gru_cell_step_f32': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
+    'tst_gather_rows_f32': ([c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
+    'tst_argmax_rows_f32': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_vp], c_int),
+    'tst_logsoftmax_topk_f32': ([c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp], c_int),
+    'tst_beam_merge': ([ctypes.POINTER(TstRows), c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
+                        c_vp], c_int),
+    'tst_greedy_select': ([c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(TstRows), c_vp], c_int),
+    'tst_retire_compact': ([ctypes.POINTER(TstRows), ctypes.POINTER(TstRows), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
+                            c_i64, c_i64, c_i64, c_i32, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_int),
+}
+
+EXPORTS = tuple(_PROTOS)
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError('%s is missing: build it with text-style-transfer_amd/csrc/build.sh (hipcc, gfx950); '
+                      'there is no non-HIP fallback' % LIB_PATH)
+_dll = ctypes.CDLL(LIB_PATH)
+for _name, (_args, _res) in _PROTOS.items():
+    _fn = getattr(_dll, _name)
+    _fn.argtypes, _fn.restype = _args, _res
+
+
+class TstError(RuntimeError):
+    pass
+
+
+def call(name, *args):
+    """Calls an entry point and raises ``TstError`` with the library's message on a non-zero status."""
+    rc = getattr(_dll, name)(*args)
+    if rc != 0:
+        raise TstError('%s failed (%d): %s' % (name, rc, _dll.tst_last_error().decode()))
+
+
+def version():
+    return _dll.tst_version()

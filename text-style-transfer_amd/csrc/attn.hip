@@ -1,0 +1,188 @@
+// Single-query attention for one decode step: one wave per (row, head).
+//
+// Memory-bound: per (row, head) the wave streams n key rows and n value rows of dh floats, each a
+// contiguous 4*dh-byte segment (self-attention finds them through the per-row ancestor table, so a beam
+// reorder never moves the cache).  Scores use 16 lanes per key position (4 positions per wave pass,
+// float4 per lane, fma chain then a 16-lane butterfly); the softmax keeps one score per lane (n <= 256);
+// the value sum runs over positions in ascending order with one fma chain per output element.
+// This fixes the arithmetic order completely (see tst_common.h).
+#include "tst_common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int MAXP = 256;  // positions per row supported by the one-score-per-lane softmax
+
+template <bool SELF, int NCH, int VEC>
+__global__ __launch_bounds__(256) void attn_step_kernel(
+    // SELF: cache [n_pos][slab_rows][3d], anc; else q [R][d], kv [n_sent][S][2d], mask, sent
+    const float* __restrict__ base, int64_t slab_stride, const int32_t* __restrict__ anc, int64_t anc_ld,
+    const float* __restrict__ qbuf, const uint8_t* __restrict__ mask, const int32_t* __restrict__ sent, int n, float* __restrict__ out,
+    int64_t R, int d, int heads, int dh, float scale) {
+    __shared__ float sc[4][MAXP];
+    __shared__ int slot[4][MAXP];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    int64_t gw = (int64_t)blockIdx.x * 4 + w;
+    const int64_t total = R * heads;
+    if (gw >= total) gw = total - 1;  // surplus waves redo the last (row, head): same values, no early exit before barriers
+    const int64_t r = gw / heads;
+    const int h = (int)(gw - r * heads);
+    const int pos = n - 1;
+
+    const float* qp;
+    const float* kbase;  // + p-dependent offset
+    int64_t ent = 0;
+    if (SELF) {
+        for (int p = lane; p < n; p += 64) slot[w][p] = (p < pos) ? anc[r * anc_ld + p] : (int)r;
+        qp = base + (int64_t)pos * slab_stride + r * 3 * d + h * dh;
+    } else {
+        ent = sent[r];
+        qp = qbuf + r * d + h * dh;
+    }
+    (void)kbase;
+    const int j = lane & 15, g = lane >> 4;
+    float4 qv[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c) {
+        const int ch = j + 16 * c;
+        qv[c] = (ch * 4 < dh) ? reinterpret_cast<const float4*>(qp)[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();
+
+    auto krow = [&](int p) -> const float* {
+        if (SELF) return base + (int64_t)p * slab_stride + (int64_t)slot[w][p] * 3 * d + d + h * dh;
+        return base + (ent * n + p) * 2 * (int64_t)d + h * dh;
+    };
+    auto vrow = [&](int p) -> const float* { return krow(p) + d; };
+
+    // scores
+    for (int p0 = 0; p0 < n; p0 += 4) {
+        const int p = p0 + g;
+        float part = 0.0f;
+        bool live = p < n;
+        if (!SELF && live && mask != nullptr && mask[ent * n + p] == 0) live = false;
+        if (live) {
+            const float4* kp = reinterpret_cast<const float4*>(krow(p));
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int ch = j + 16 * c;
+                if (ch * 4 < dh) {
+                    const float4 kv = kp[ch];
+                    part = __builtin_fmaf(qv[c].x, kv.x, part);
+                    part = __builtin_fmaf(qv[c].y, kv.y, part);
+                    part = __builtin_fmaf(qv[c].z, kv.z, part);
+                    part = __builtin_fmaf(qv[c].w, kv.w, part);
+                }
+            }
+        }
+        part = group16_sum_butterfly(part);
+        if (j == 0 && p < n) sc[w][p] = live ? part * scale : -INFINITY;
+    }
+    __syncthreads();
+
+    // softmax weights, one score per lane and 64-position block
+    float s[MAXP / 64];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXP / 64; ++i) {
+        const int p = lane + 64 * i;
+        s[i] = p < n ? sc[w][p] : -INFINITY;
+        m = fmaxf(m, s[i]);
+    }
+    m = wave_max(m);
+    float part = 0.0f;
+#pragma unroll
+    for (int i = 0; i < MAXP / 64; ++i) {
+        const int p = lane + 64 * i;
+        const float e = p < n ? d_exp(s[i] - m) : 0.0f;
+        s[i] = e;
+        part = part + e;
+    }
+    const float sum = wave_sum_butterfly(part);
+#pragma unroll
+    for (int i = 0; i < MAXP / 64; ++i) {
+        const int p = lane + 64 * i;
+        if (p < n) sc[w][p] = s[i] / sum;
+    }
+    __syncthreads();
+
+    // weighted value sum, positions ascending
+    float* orow = out + r * d + h * dh;
+    for (int c0 = lane * VEC; c0 < dh; c0 += 64 * VEC) {
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.0f;
+#pragma unroll 4
+        for (int p = 0; p < n; ++p) {
+            const float wp = sc[w][p];
+            const float* vp = vrow(p) + c0;
+            if (VEC == 4) {
+                const float4 v = *reinterpret_cast<const float4*>(vp);
+                acc[0] = __builtin_fmaf(wp, v.x, acc[0]);
+                acc[1 % VEC] = __builtin_fmaf(wp, v.y, acc[1 % VEC]);
+                acc[2 % VEC] = __builtin_fmaf(wp, v.z, acc[2 % VEC]);
+                acc[3 % VEC] = __builtin_fmaf(wp, v.w, acc[3 % VEC]);
+            } else if (VEC == 2) {
+                const float2 v = *reinterpret_cast<const float2*>(vp);
+                acc[0] = __builtin_fmaf(wp, v.x, acc[0]);
+                acc[1 % VEC] = __builtin_fmaf(wp, v.y, acc[1 % VEC]);
+            } else {
+                acc[0] = __builtin_fmaf(wp, vp[0], acc[0]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) orow[c0 + e] = acc[e];
+    }
+}
+
+template <bool SELF>
+int launch_attn(const float* base, int64_t slab_stride, const int32_t* anc, int64_t anc_ld, const float* q,
+                const uint8_t* mask, const int32_t* sent, int64_t n, float* out, int64_t R, int64_t d, int64_t heads,
+                hipStream_t stream, const char* name) {
+    const int64_t dh = d / heads;
+    const float scale = 1.0f / sqrtf((float)dh);
+    const unsigned grid = (unsigned)((R * heads + 3) / 4);
+    const int nch = (int)((dh + 63) / 64);
+    const int vec = (dh % 256 == 0) ? 4 : (dh % 128 == 0) ? 2 : 1;
+#define TST_ATTN_CASE(NCH_, VEC_)                                                                                        \
+    hipLaunchKernelGGL((attn_step_kernel<SELF, NCH_, VEC_>), dim3(grid), dim3(256), 0, stream, base, slab_stride, anc,  \
+                       anc_ld, q, mask, sent, (int)n, out, R, (int)d, (int)heads, (int)dh, scale)
+    if (nch == 1 && vec == 1) TST_ATTN_CASE(1, 1);
+    else if (nch == 2 && vec == 2) TST_ATTN_CASE(2, 2);
+    else if (nch == 2 && vec == 1) TST_ATTN_CASE(2, 1);
+    else if (nch == 3 && vec == 1) TST_ATTN_CASE(3, 1);
+    else if (nch == 4 && vec == 4) TST_ATTN_CASE(4, 4);
+    else if (nch == 4 && vec == 1) TST_ATTN_CASE(4, 1);
+    else {
+        tst_set_error("%s: head size %lld not supported (multiple of 4, at most 256)", name, (long long)dh);
+        return TST_ERR_UNSUPPORTED;
+    }
+#undef TST_ATTN_CASE
+    return tst_after_launch(name);
+}
+
+}  // namespace
+
+extern "C" int tst_attn_self_step_f32(const float* cache, int64_t slab_rows, const int32_t* anc, int64_t anc_ld,
+                                      int64_t pos, float* out, int64_t R, int64_t d, int64_t heads, void* stream) {
+    TST_REQUIRE(cache && out && (anc || pos == 0), TST_ERR_ARG, "tst_attn_self_step_f32: null pointer");
+    TST_REQUIRE(R >= 0 && R <= slab_rows && d > 0 && heads > 0 && d % heads == 0 && (d / heads) % 4 == 0 && pos >= 0,
+                TST_ERR_ARG, "tst_attn_self_step_f32: bad sizes");
+    TST_REQUIRE(pos + 1 <= MAXP && pos <= anc_ld, TST_ERR_UNSUPPORTED, "tst_attn_self_step_f32: at most %d positions", MAXP);
+    TST_REQUIRE(tst_aligned16(cache) && tst_aligned16(out), TST_ERR_ARG, "tst_attn_self_step_f32: alignment");
+    if (R == 0) return TST_OK;
+    return launch_attn<true>(cache, slab_rows * 3 * d, anc, anc_ld, nullptr, nullptr, nullptr, pos + 1, out, R, d, heads,
+                             (hipStream_t)stream, "tst_attn_self_step_f32");
+}
+
+extern "C" int tst_attn_cross_step_f32(const float* q, const float* kv, const uint8_t* mask, const int32_t* sent,
+                                       int64_t S, float* out, int64_t R, int64_t d, int64_t heads, void* stream) {
+    TST_REQUIRE(q && kv && sent && out, TST_ERR_ARG, "tst_attn_cross_step_f32: null pointer");
+    TST_REQUIRE(R >= 0 && d > 0 && heads > 0 && d % heads == 0 && (d / heads) % 4 == 0 && S > 0, TST_ERR_ARG,
+                "tst_attn_cross_step_f32: bad sizes");
+    TST_REQUIRE(S <= MAXP, TST_ERR_UNSUPPORTED, "tst_attn_cross_step_f32: at most %d source positions", MAXP);
+    TST_REQUIRE(tst_aligned16(q) && tst_aligned16(kv) && tst_aligned16(out), TST_ERR_ARG, "tst_attn_cross_step_f32: alignment");
+    if (R == 0) return TST_OK;
+    return launch_attn<false>(kv, 0, nullptr, 0, q, mask, sent, S, out, R, d, heads, (hipStream_t)stream,
+                              "tst_attn_cross_step_f32");
+}

@@ -1,0 +1,141 @@
+// fp32 GEMM on the gfx950 matrix cores: C = epilogue(bias + A * Wt).
+//
+// v_mfma_f32_32x32x2_f32 accumulates exactly like a k-ordered fmaf chain (one rounding per term),
+// so every output element is  acc = bias[n]; for k ascending: acc = fma(A[m][k], Wt[k][n], acc)
+// whatever the tiling.  Tile: 128 x 128 x 16 per 256-thread workgroup; 4 waves as 2 (M) x 2 (N), each
+// wave owns 64 x 64 = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator registers).  A and Wt tiles are
+// staged through registers into k-major LDS images ([k][m] and [k][n]) so that the one-float-per-lane
+// MFMA operands are conflict-free ds_read_b32; global loads of tile t+1 are in flight while tile t is
+// multiplied (two LDS buffers, one barrier per tile).  Workgroups are renumbered so that each XCD
+// walks a contiguous, m-grouped range of tiles and re-reads A / Wt panels from its own L2.
+#include "tst_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 16, LDT = 132, GROUP_M = 16;
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
+                                                       const float* __restrict__ W, int64_t ldw,
+                                                       const float* __restrict__ bias, const float* res, int64_t ldr,
+                                                       float* C, int64_t ldc, int M, int N, int K, int act, int tiles_m,
+                                                       int tiles_n) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDT];
+
+    // workgroup id -> logical tile index: consecutive ids go to different XCDs, so give every XCD a
+    // contiguous range (bijective for any grid size), then walk tiles in groups of GROUP_M rows.
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
+    const int lb = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    const int per_group = GROUP_M * tiles_n;
+    const int first_m = (lb / per_group) * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (lb % per_group) % gsz;
+    const int tn = (lb % per_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // staging registers for the next tile: 2 float4 of A (rows ar0/ar1, k offset akq) and 2 of Wt
+    float4 ra0, ra1, rb0, rb1;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int ar0 = t >> 2, ar1 = (t + 256) >> 2, akq = (t & 3) * 4;
+    const int bk0 = t >> 5, bk1 = (t + 256) >> 5, bnq = (t & 31) * 4;
+    const float* a_row0 = A + (int64_t)min(m0 + ar0, M - 1) * lda;
+    const float* a_row1 = A + (int64_t)min(m0 + ar1, M - 1) * lda;
+    const bool b_in = n0 + bnq < ldw;
+
+#define TST_LOAD_TILE(k0)                                                                                       \
+    do {                                                                                                        \
+        const int gk_ = (k0) + akq;                                                                             \
+        ra0 = gk_ < K ? *reinterpret_cast<const float4*>(a_row0 + gk_) : zero4;                                 \
+        ra1 = gk_ < K ? *reinterpret_cast<const float4*>(a_row1 + gk_) : zero4;                                 \
+        rb0 = (b_in && (k0) + bk0 < K) ? *reinterpret_cast<const float4*>(W + (int64_t)((k0) + bk0) * ldw + n0 + bnq) : zero4; \
+        rb1 = (b_in && (k0) + bk1 < K) ? *reinterpret_cast<const float4*>(W + (int64_t)((k0) + bk1) * ldw + n0 + bnq) : zero4; \
+    } while (0)
+#define TST_STORE_TILE(buf)                                                                                     \
+    do {                                                                                                        \
+        As[buf][akq + 0][ar0] = ra0.x; As[buf][akq + 1][ar0] = ra0.y;                                           \
+        As[buf][akq + 2][ar0] = ra0.z; As[buf][akq + 3][ar0] = ra0.w;                                           \
+        As[buf][akq + 0][ar1] = ra1.x; As[buf][akq + 1][ar1] = ra1.y;                                           \
+        As[buf][akq + 2][ar1] = ra1.z; As[buf][akq + 3][ar1] = ra1.w;                                           \
+        *reinterpret_cast<float4*>(&Bs[buf][bk0][bnq]) = rb0;                                                   \
+        *reinterpret_cast<float4*>(&Bs[buf][bk1][bnq]) = rb1;                                                   \
+    } while (0)
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+        const float b = (bias != nullptr && col < N) ? bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = b;
+    }
+
+    const int nkt = (K + BK - 1) / BK;
+    TST_LOAD_TILE(0);
+    TST_STORE_TILE(0);
+    __syncthreads();
+    const int arow = wm * 64 + (lane & 31), bcol = wn * 64 + (lane & 31), khalf = lane >> 5;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nkt) TST_LOAD_TILE((kt + 1) * BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const int kr = kk + khalf;
+            const float a0 = As[buf][kr][arow], a1 = As[buf][kr][arow + 32];
+            const float b0 = Bs[buf][kr][bcol], b1 = Bs[buf][kr][bcol + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (kt + 1 < nkt) TST_STORE_TILE(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < M && col < N) {
+                    float v = acc[i][j][r];
+                    if (act == 1) v = v > 0.0f ? v : 0.0f;
+                    if (res != nullptr) v = v + res[(int64_t)row * ldr + col];
+                    C[(int64_t)row * ldc + col] = v;
+                }
+            }
+        }
+}
+
+}  // namespace
+
+extern "C" int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias,
+                                 const float* res, int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                 int act, void* stream) {
+    TST_REQUIRE(A && Wt && C, TST_ERR_ARG, "tst_gemm_mfma_f32: null pointer");
+    TST_REQUIRE(M >= 0 && N > 0 && K > 0, TST_ERR_ARG, "tst_gemm_mfma_f32: bad sizes M=%lld N=%lld K=%lld", (long long)M,
+                (long long)N, (long long)K);
+    TST_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= K && ldw >= N && ldc >= N, TST_ERR_ARG,
+                "tst_gemm_mfma_f32: K, lda, ldw must be multiples of 4 and lda >= K, ldw >= N, ldc >= N");
+    TST_REQUIRE(tst_aligned16(A) && tst_aligned16(Wt), TST_ERR_ARG, "tst_gemm_mfma_f32: A and Wt must be 16-byte aligned");
+    TST_REQUIRE(res == nullptr || ldr >= N, TST_ERR_ARG, "tst_gemm_mfma_f32: ldr < N");
+    TST_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_f32: size");
+    if (M == 0) return TST_OK;
+    const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+    TST_REQUIRE(tiles_m * tiles_n < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_f32: grid too large");
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, (hipStream_t)stream, A, lda, Wt,
+                       ldw, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, act, (int)tiles_m, (int)tiles_n);
+    return tst_after_launch("tst_gemm_mfma_f32");
+}

@@ -1,0 +1,152 @@
+// Row-wise HBM-bound kernels: embedding gather + positional add, LayerNorm, GRU cell update, row gather.
+// All of them move 16 bytes per lane per access; none has cross-workgroup reuse.
+#include "tst_common.h"
+
+namespace {
+
+// one thread per float4 of the output
+__global__ __launch_bounds__(256) void embed_posadd_kernel(const int32_t* __restrict__ tok, const float* __restrict__ emb,
+                                                           const float* __restrict__ pe, const int32_t* __restrict__ pos,
+                                                           float scale, float* __restrict__ x, int64_t R, int d4, int64_t V) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * d4) return;
+    const int64_t r = i / d4;
+    const int c4 = (int)(i - r * d4);
+    int64_t id = tok[r];
+    id = id < 0 ? 0 : (id >= V ? V - 1 : id);
+    float4 e = reinterpret_cast<const float4*>(emb + id * (int64_t)d4 * 4)[c4];
+    float4 o;
+    o.x = e.x * scale; o.y = e.y * scale; o.z = e.z * scale; o.w = e.w * scale;
+    if (pe != nullptr) {
+        const float4 p = reinterpret_cast<const float4*>(pe)[(pos != nullptr ? (int64_t)pos[r] * d4 : 0) + c4];
+        o.x = o.x + p.x; o.y = o.y + p.y; o.z = o.z + p.z; o.w = o.w + p.w;
+    }
+    reinterpret_cast<float4*>(x)[i] = o;
+}
+
+// one wave per row; lane l owns the float4 chunks l, l + 64, ... (element c -> partial (c / 4) % 64)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                        const float* __restrict__ b, float eps, float* __restrict__ y,
+                                                        int64_t R, int d4) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= R) return;
+    const float4* xr = reinterpret_cast<const float4*>(x) + r * d4;
+    float p = 0.0f;
+    for (int c = lane; c < d4; c += 64) {
+        const float4 v = xr[c];
+        p = p + v.x; p = p + v.y; p = p + v.z; p = p + v.w;
+    }
+    const float d = (float)(d4 * 4);
+    const float mean = wave_sum_butterfly(p) / d;
+    p = 0.0f;
+    for (int c = lane; c < d4; c += 64) {
+        const float4 v = xr[c];
+        float t;
+        t = v.x - mean; p = __builtin_fmaf(t, t, p);
+        t = v.y - mean; p = __builtin_fmaf(t, t, p);
+        t = v.z - mean; p = __builtin_fmaf(t, t, p);
+        t = v.w - mean; p = __builtin_fmaf(t, t, p);
+    }
+    const float var = wave_sum_butterfly(p) / d;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    float4* yr = reinterpret_cast<float4*>(y) + r * d4;
+    for (int c = lane; c < d4; c += 64) {
+        const float4 v = xr[c];
+        const float4 gg = reinterpret_cast<const float4*>(g)[c];
+        const float4 bb = reinterpret_cast<const float4*>(b)[c];
+        float4 o;
+        o.x = __builtin_fmaf((v.x - mean) * rstd, gg.x, bb.x);
+        o.y = __builtin_fmaf((v.y - mean) * rstd, gg.y, bb.y);
+        o.z = __builtin_fmaf((v.z - mean) * rstd, gg.z, bb.z);
+        o.w = __builtin_fmaf((v.w - mean) * rstd, gg.w, bb.w);
+        yr[c] = o;
+    }
+}
+
+__device__ __forceinline__ float gru_elem(float ir, float iz, float in, float hr, float hz, float hn, float h) {
+    const float rg = d_sigmoid(ir + hr);
+    const float zg = d_sigmoid(iz + hz);
+    const float ng = d_tanh(__builtin_fmaf(rg, hn, in));
+    return __builtin_fmaf(zg, h, (1.0f - zg) * ng);
+}
+
+// one thread per float4 of h
+__global__ __launch_bounds__(256) void gru_cell_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
+                                                       const float* h, float* h_out, int64_t R, int H4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * H4) return;
+    const int64_t r = i / H4;
+    const int c4 = (int)(i - r * H4);
+    const float4* a = reinterpret_cast<const float4*>(gi) + r * 3 * H4;
+    const float4* b = reinterpret_cast<const float4*>(gh) + r * 3 * H4;
+    const float4 ir = a[c4], iz = a[H4 + c4], in = a[2 * H4 + c4];
+    const float4 hr = b[c4], hz = b[H4 + c4], hn = b[2 * H4 + c4];
+    const float4 hv = reinterpret_cast<const float4*>(h)[i];
+    float4 o;
+    o.x = gru_elem(ir.x, iz.x, in.x, hr.x, hz.x, hn.x, hv.x);
+    o.y = gru_elem(ir.y, iz.y, in.y, hr.y, hz.y, hn.y, hv.y);
+    o.z = gru_elem(ir.z, iz.z, in.z, hr.z, hz.z, hn.z, hv.z);
+    o.w = gru_elem(ir.w, iz.w, in.w, hr.w, hz.w, hn.w, hv.w);
+    reinterpret_cast<float4*>(h_out)[i] = o;
+}
+
+__global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                          float* __restrict__ dst, int64_t R, int w4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * w4) return;
+    const int64_t r = i / w4;
+    const int c4 = (int)(i - r * w4);
+    reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[(int64_t)idx[r] * w4 + c4];
+}
+
+inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+}  // namespace
+
+extern "C" int tst_embed_posadd_f32(const int32_t* tok, const float* emb, const float* pe, const int32_t* pos, float scale,
+                                    float* x, int64_t R, int64_t d, int64_t V, void* stream) {
+    TST_REQUIRE(tok && emb && x && (pe || !pos), TST_ERR_ARG, "tst_embed_posadd_f32: null pointer");
+    TST_REQUIRE(R >= 0 && d > 0 && d % 4 == 0 && V > 0, TST_ERR_ARG, "tst_embed_posadd_f32: need d %% 4 == 0, V > 0");
+    TST_REQUIRE(tst_aligned16(emb) && tst_aligned16(x) && tst_aligned16(pe), TST_ERR_ARG, "tst_embed_posadd_f32: alignment");
+    TST_REQUIRE(R * (d / 4) < (1ll << 31) * 256, TST_ERR_UNSUPPORTED, "tst_embed_posadd_f32: too large");
+    if (R == 0) return TST_OK;
+    hipLaunchKernelGGL(embed_posadd_kernel, dim3(blocks_for(R * (d / 4), 256)), dim3(256), 0, (hipStream_t)stream, tok, emb,
+                       pe, pos, scale, x, R, (int)(d / 4), V);
+    return tst_after_launch("tst_embed_posadd_f32");
+}
+
+extern "C" int tst_layernorm_f32(const float* x, const float* gamma, const float* beta, float eps, float* y, int64_t R,
+                                 int64_t d, void* stream) {
+    TST_REQUIRE(x && gamma && beta && y, TST_ERR_ARG, "tst_layernorm_f32: null pointer");
+    TST_REQUIRE(R >= 0 && d > 0 && d % 4 == 0, TST_ERR_ARG, "tst_layernorm_f32: need d %% 4 == 0");
+    TST_REQUIRE(tst_aligned16(x) && tst_aligned16(y) && tst_aligned16(gamma) && tst_aligned16(beta), TST_ERR_ARG,
+                "tst_layernorm_f32: alignment");
+    if (R == 0) return TST_OK;
+    hipLaunchKernelGGL(layernorm_kernel, dim3(blocks_for(R, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, y,
+                       R, (int)(d / 4));
+    return tst_after_launch("tst_layernorm_f32");
+}
+
+extern "C" int tst_gru_cell_step_f32(const float* gi, const float* gh, const float* h, float* h_out, int64_t R, int64_t H,
+                                     void* stream) {
+    TST_REQUIRE(gi && gh && h && h_out, TST_ERR_ARG, "tst_gru_cell_step_f32: null pointer");
+    TST_REQUIRE(R >= 0 && H > 0 && H % 4 == 0, TST_ERR_ARG, "tst_gru_cell_step_f32: need H %% 4 == 0");
+    TST_REQUIRE(tst_aligned16(gi) && tst_aligned16(gh) && tst_aligned16(h) && tst_aligned16(h_out), TST_ERR_ARG,
+                "tst_gru_cell_step_f32: alignment");
+    if (R == 0) return TST_OK;
+    hipLaunchKernelGGL(gru_cell_kernel, dim3(blocks_for(R * (H / 4), 256)), dim3(256), 0, (hipStream_t)stream, gi, gh, h,
+                       h_out, R, (int)(H / 4));
+    return tst_after_launch("tst_gru_cell_step_f32");
+}
+
+extern "C" int tst_gather_rows_f32(const float* src, const int32_t* idx, float* dst, int64_t R, int64_t width,
+                                   void* stream) {
+    TST_REQUIRE(src && idx && dst && src != dst, TST_ERR_ARG, "tst_gather_rows_f32: null or aliased pointer");
+    TST_REQUIRE(R >= 0 && width > 0 && width % 4 == 0, TST_ERR_ARG, "tst_gather_rows_f32: need width %% 4 == 0");
+    TST_REQUIRE(tst_aligned16(src) && tst_aligned16(dst), TST_ERR_ARG, "tst_gather_rows_f32: alignment");
+    if (R == 0) return TST_OK;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks_for(R * (width / 4), 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       idx, dst, R, (int)(width / 4));
+    return tst_after_launch("tst_gather_rows_f32");
+}

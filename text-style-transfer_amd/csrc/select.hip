@@ -1,0 +1,450 @@
+// Token selection and decode-loop bookkeeping on the device: arg-max, log-sum-exp + top-k over the
+// vocabulary (the HBM-bound pass over the [rows, V] logits), beam merge, retirement of finished
+// sentences and batch compaction.  No MFMA here: coalesced 16-byte reads, wave butterflies, LDS only
+// to combine the four waves of a workgroup.
+#include "tst_common.h"
+#include <limits.h>
+#include <math.h>
+
+namespace {
+
+// (value desc, index asc) ordering
+__device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
+
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(v, off, 64);
+        const int oi = __shfl_xor(i, off, 64);
+        if (better(ov, oi, v, i)) { v = ov; i = oi; }
+    }
+}
+
+// block-wide (256 threads) argmax; result valid in every thread. red_* are LDS arrays of 4.
+__device__ __forceinline__ void block_argmax(float& v, int& i, float* red_v, int* red_i) {
+    wave_argmax(v, i);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();  // protects red_* against the previous round's readers
+    if ((threadIdx.x & 63) == 0) { red_v[w] = v; red_i[w] = i; }
+    __syncthreads();
+    v = red_v[0]; i = red_i[0];
+#pragma unroll
+    for (int q = 1; q < 4; ++q)
+        if (better(red_v[q], red_i[q], v, i)) { v = red_v[q]; i = red_i[q]; }
+}
+
+// loads chunk c (elements 4c..4c+3) of a row; elements at or beyond V read as -inf
+__device__ __forceinline__ float4 load_chunk(const float* xr, int c, int V, bool vec_ok) {
+    if (vec_ok && 4 * c + 3 < V) return reinterpret_cast<const float4*>(xr)[c];
+    float4 v;
+    v.x = 4 * c + 0 < V ? xr[4 * c + 0] : -INFINITY;
+    v.y = 4 * c + 1 < V ? xr[4 * c + 1] : -INFINITY;
+    v.z = 4 * c + 2 < V ? xr[4 * c + 2] : -INFINITY;
+    v.w = 4 * c + 3 < V ? xr[4 * c + 3] : -INFINITY;
+    return v;
+}
+
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int64_t ld, int V,
+                                                          int32_t* __restrict__ tok, int vec_ok) {
+    __shared__ float red_v[4];
+    __shared__ int red_i[4];
+    const float* xr = x + (int64_t)blockIdx.x * ld;
+    const int nch = (V + 3) >> 2;
+    float bv = -INFINITY;
+    int bi = INT_MAX;
+    for (int c = threadIdx.x; c < nch; c += 256) {
+        const float4 v = load_chunk(xr, c, V, vec_ok != 0);
+        if (v.x > bv) { bv = v.x; bi = 4 * c; }
+        if (v.y > bv) { bv = v.y; bi = 4 * c + 1; }
+        if (v.z > bv) { bv = v.z; bi = 4 * c + 2; }
+        if (v.w > bv) { bv = v.w; bi = 4 * c + 3; }
+    }
+    block_argmax(bv, bi, red_v, red_i);
+    if (threadIdx.x == 0) tok[blockIdx.x] = bi == INT_MAX ? 0 : bi;
+}
+
+constexpr int MAXC = 32;    // resident chunks per thread: rows of up to 256 * 32 * 4 = 32768 floats stay in registers
+constexpr int CAND_CAP = 1024;  // LDS candidate list of the top-k filter
+
+// One workgroup per row; thread t owns the float4 chunks t, t + 256, ... of the row.
+//  pass A  row maximum m, and tau = the K-th largest of the 256 per-thread maxima: at least K elements
+//          are >= tau, so the K largest elements of the row are all >= tau.
+//  pass B  sum of exp(x - m) per thread in ascending element order (wave butterfly, then the four waves
+//          left to right), while elements >= tau go to a candidate list in LDS (normally ~K entries).
+//  select  K rounds of workgroup arg-max over the candidates, (value desc, index asc).  If the list
+//          overflows (many equal values), K rounds over the whole row instead: each round takes the best
+//          element after the previous winner in that order.
+// The row is read from HBM once when it fits the registers (RESIDENT), otherwise re-read per pass.
+template <int K, bool RESIDENT>
+__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __restrict__ x, int64_t ld, int V,
+                                                              float* __restrict__ top_val, int32_t* __restrict__ top_idx,
+                                                              float* __restrict__ lse, int vec_ok) {
+    __shared__ float red_v[4];
+    __shared__ int red_i[4];
+    __shared__ float red_s[4];
+    __shared__ float cand_v[CAND_CAP];
+    __shared__ int cand_i[CAND_CAP];
+    __shared__ int cand_n;
+    const int t = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    const float* xr = x + r * ld;
+    const int nch = (V + 3) >> 2;
+    const bool vok = vec_ok != 0;
+    float4 buf[RESIDENT ? MAXC : 1];
+    if (t == 0) cand_n = 0;
+
+    float tmax = -INFINITY;
+    if (RESIDENT) {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = t + 256 * i;
+            float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            if (c < nch) v = load_chunk(xr, c, V, vok);
+            buf[i] = v;
+            tmax = fmaxf(tmax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        }
+    } else {
+        for (int c = t; c < nch; c += 256) {
+            const float4 v = load_chunk(xr, c, V, vok);
+            tmax = fmaxf(tmax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+        }
+    }
+    float m = -INFINITY, tau = -INFINITY;
+    for (int o = 0; o < K; ++o) {
+        float v = tmax;
+        int id = t;
+        block_argmax(v, id, red_v, red_i);
+        if (o == 0) m = v;
+        tau = v;
+        if (id == t) tmax = -INFINITY;
+    }
+
+    float part = 0.0f;
+#define TST_PASS_B(v, c)                                                                        \
+    do {                                                                                        \
+        part = part + d_exp((v).x - m);                                                         \
+        part = part + d_exp((v).y - m);                                                         \
+        part = part + d_exp((v).z - m);                                                         \
+        part = part + d_exp((v).w - m);                                                         \
+        const float e_[4] = {(v).x, (v).y, (v).z, (v).w};                                       \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                        \
+            if (e_[q_] >= tau && 4 * (c) + q_ < V) {                                            \
+                const int at_ = atomicAdd(&cand_n, 1);                                          \
+                if (at_ < CAND_CAP) { cand_v[at_] = e_[q_]; cand_i[at_] = 4 * (c) + q_; }       \
+            }                                                                                   \
+    } while (0)
+    if (RESIDENT) {
+#pragma unroll
+        for (int i = 0; i < MAXC; ++i) {
+            const int c = t + 256 * i;
+            if (c < nch) TST_PASS_B(buf[i], c);
+        }
+    } else {
+        for (int c = t; c < nch; c += 256) {
+            const float4 v = load_chunk(xr, c, V, vok);
+            TST_PASS_B(v, c);
+        }
+    }
+#undef TST_PASS_B
+    part = wave_sum_butterfly(part);
+    if ((t & 63) == 0) red_s[t >> 6] = part;
+    __syncthreads();
+    if (t == 0) {
+        const float total = ((red_s[0] + red_s[1]) + red_s[2]) + red_s[3];
+        lse[r] = m + d_log(total);
+    }
+    const int ncand = cand_n;
+
+    if (ncand <= CAND_CAP) {
+        for (int o = 0; o < K; ++o) {
+            float bv = -INFINITY;
+            int bi = INT_MAX, be = -1;
+            for (int e = t; e < ncand; e += 256)
+                if (better(cand_v[e], cand_i[e], bv, bi)) { bv = cand_v[e]; bi = cand_i[e]; be = e; }
+            const int mine = bi;
+            block_argmax(bv, bi, red_v, red_i);
+            if (be >= 0 && bi == mine) { cand_v[be] = -INFINITY; cand_i[be] = INT_MAX; }
+            if (t == 0) { top_val[r * K + o] = bv; top_idx[r * K + o] = bi == INT_MAX ? -1 : bi; }
+        }
+    } else {
+        float lastv = INFINITY;
+        int lasti = -1;
+        for (int o = 0; o < K; ++o) {
+            float bv = -INFINITY;
+            int bi = INT_MAX;
+#define TST_SCAN(v, c)                                                                                  \
+    do {                                                                                                \
+        const float e_[4] = {(v).x, (v).y, (v).z, (v).w};                                               \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                              \
+            const int id_ = 4 * (c) + q_;                                                               \
+            const bool after_ = e_[q_] < lastv || (e_[q_] == lastv && id_ > lasti);                     \
+            if (id_ < V && after_ && better(e_[q_], id_, bv, bi)) { bv = e_[q_]; bi = id_; }            \
+        }                                                                                               \
+    } while (0)
+            for (int c = t; c < nch; c += 256) {  // rare path: re-read the row instead of keeping it live
+                const float4 v = load_chunk(xr, c, V, vok);
+                TST_SCAN(v, c);
+            }
+#undef TST_SCAN
+            block_argmax(bv, bi, red_v, red_i);
+            lastv = bv; lasti = bi;
+            if (t == 0) { top_val[r * K + o] = bv; top_idx[r * K + o] = bi == INT_MAX ? -1 : bi; }
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void greedy_select_kernel(const int32_t* __restrict__ am, int64_t n, int32_t eos,
+                                                            int32_t* parent, int32_t* tok, float* score, int32_t* fin,
+                                                            int32_t* nemit, tst_rows cur) {
+    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n) return;
+    const int32_t tk = am[r];
+    parent[r] = (int32_t)r;
+    tok[r] = tk;
+    score[r] = 0.0f;
+    fin[r] = tk == eos ? 1 : 0;
+    nemit[r] = cur.nemit[r] + 1;
+}
+
+// one thread per sentence; offers are enumerated in (beam, rank) order and picked with a strict compare,
+// which makes ties go to the lower beam, then the lower rank
+__global__ __launch_bounds__(256) void beam_merge_kernel(tst_rows cur, const float* __restrict__ top_val,
+                                                         const int32_t* __restrict__ top_idx,
+                                                         const float* __restrict__ lse, int64_t n_sent, int k, int step,
+                                                         int32_t eos, int32_t* parent, int32_t* tok, float* score,
+                                                         int32_t* fin, int32_t* nemit) {
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= n_sent) return;
+    const int64_t base = a * k;
+    float cv[64];
+    int8_t cj[64];
+    int32_t ct[64];
+    int nc = 0;
+    for (int j = 0; j < k; ++j) {
+        const int64_t row = base + j;
+        if (cur.fin[row]) {
+            cv[nc] = cur.score[row]; cj[nc] = (int8_t)j; ct[nc] = -1; ++nc;
+        } else if (step == 0 && j > 0) {
+            continue;
+        } else {
+            const float sc = cur.score[row], ls = lse[row];
+            for (int rk = 0; rk < k; ++rk) {
+                cv[nc] = sc + (top_val[row * k + rk] - ls);
+                cj[nc] = (int8_t)j; ct[nc] = top_idx[row * k + rk]; ++nc;
+            }
+        }
+    }
+    unsigned long long taken = 0ull;
+    for (int o = 0; o < k; ++o) {
+        int best = -1;
+        for (int c = 0; c < nc; ++c)
+            if (!((taken >> c) & 1ull) && (best < 0 || cv[c] > cv[best])) best = c;
+        const int64_t dst = base + o;
+        if (best < 0) {  // fewer offers than beams: pad with an ended, worthless hypothesis
+            parent[dst] = (int32_t)base; tok[dst] = eos; score[dst] = -INFINITY; fin[dst] = 1; nemit[dst] = 0;
+            continue;
+        }
+        taken |= 1ull << best;
+        const int64_t prow = base + cj[best];
+        parent[dst] = (int32_t)prow;
+        score[dst] = cv[best];
+        if (ct[best] < 0) {
+            tok[dst] = eos; fin[dst] = 1; nemit[dst] = cur.nemit[prow];
+        } else {
+            tok[dst] = ct[best]; fin[dst] = ct[best] == eos ? 1 : 0; nemit[dst] = cur.nemit[prow] + 1;
+        }
+    }
+}
+
+// one thread per sentence: decide whether it ended, and if so write its best beam to the outputs
+__global__ __launch_bounds__(256) void finish_kernel(tst_rows cur, const int32_t* __restrict__ parent,
+                                                     const int32_t* __restrict__ tok, const float* __restrict__ score,
+                                                     const int32_t* __restrict__ fin, const int32_t* __restrict__ nemit,
+                                                     const float* __restrict__ lp, int64_t n_sent, int k, int T,
+                                                     int last_step, int32_t* out_tok, int32_t* out_len, float* out_score,
+                                                     int32_t* alive) {
+    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (a >= n_sent) return;
+    const int64_t base = a * k;
+    bool all_fin = true;
+    for (int j = 0; j < k; ++j) all_fin = all_fin && fin[base + j] != 0;
+    const bool done = all_fin || last_step != 0;
+    alive[a] = done ? 0 : 1;
+    if (!done) return;
+    int best = 0;
+    float br = score[base] / lp[nemit[base]];
+    for (int j = 1; j < k; ++j) {
+        const float rj = score[base + j] / lp[nemit[base + j]];
+        if (rj > br) { br = rj; best = j; }
+    }
+    const int64_t sel = base + best;
+    const int64_t p = parent[sel];
+    const int64_t s = cur.sent[p];
+    const int plen = 1 + cur.nemit[p] - cur.fin[p];
+    const int olen = 1 + nemit[sel] - fin[sel];
+    for (int i = 0; i < plen; ++i) out_tok[s * (T + 1) + i] = cur.hist[p * (T + 1) + i];
+    if (olen > plen) out_tok[s * (T + 1) + plen] = tok[sel];
+    out_len[s] = olen;
+    out_score[s] = score[sel];
+}
+
+// exclusive prefix sum of alive[0..n) by one workgroup of 1024 threads; pos[a] = new sentence index
+__global__ __launch_bounds__(1024) void scan_alive_kernel(const int32_t* __restrict__ alive, int32_t* __restrict__ pos,
+                                                          int64_t n, int32_t* __restrict__ n_alive) {
+    __shared__ int wsum[16];
+    const int t = threadIdx.x;
+    const int64_t per = (n + 1023) / 1024;
+    const int64_t lo = (int64_t)t * per, hi = lo + per < n ? lo + per : n;
+    int local = 0;
+    for (int64_t i = lo; i < hi; ++i) local += alive[i];
+    // inclusive scan of `local` across the workgroup
+    int inc = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        if ((t & 63) >= off) inc += o;
+    }
+    if ((t & 63) == 63) wsum[t >> 6] = inc;
+    __syncthreads();
+    int wbase = 0;
+    for (int q = 0; q < (t >> 6); ++q) wbase += wsum[q];
+    int run = wbase + inc - local;
+    for (int64_t i = lo; i < hi; ++i) { pos[i] = run; run += alive[i]; }
+    if (t == 1023) *n_alive = wbase + inc;
+}
+
+// one wave per new row slot (a, j) of a surviving sentence
+__global__ __launch_bounds__(256) void gather_state_kernel(tst_rows cur, tst_rows nxt, const int32_t* __restrict__ parent,
+                                                           const int32_t* __restrict__ tok, const float* __restrict__ score,
+                                                           const int32_t* __restrict__ fin, const int32_t* __restrict__ nemit,
+                                                           const int32_t* __restrict__ alive, const int32_t* __restrict__ pos,
+                                                           int64_t n_rows, int k, int step, int T, int32_t* row_parent) {
+    const int lane = threadIdx.x & 63;
+    const int64_t slot = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (slot >= n_rows) return;
+    const int64_t a = slot / k;
+    if (!alive[a]) return;
+    const int j = (int)(slot - a * k);
+    const int64_t dst = (int64_t)pos[a] * k + j;
+    const int64_t p = parent[slot];
+    const int plen = 1 + cur.nemit[p] - cur.fin[p];
+    const int nlen = 1 + nemit[slot] - fin[slot];
+    for (int i = lane; i < plen; i += 64) nxt.hist[dst * (T + 1) + i] = cur.hist[p * (T + 1) + i];
+    if (cur.anc != nullptr) {
+        for (int i = lane; i < step; i += 64) nxt.anc[dst * T + i] = cur.anc[p * T + i];
+    }
+    if (lane == 0) {
+        if (nlen > plen) nxt.hist[dst * (T + 1) + plen] = tok[slot];
+        if (cur.anc != nullptr && step < T) nxt.anc[dst * T + step] = (int32_t)p;
+        nxt.sent[dst] = cur.sent[p];
+        nxt.tok[dst] = tok[slot];
+        nxt.score[dst] = score[slot];
+        nxt.fin[dst] = fin[slot];
+        nxt.nemit[dst] = nemit[slot];
+        row_parent[dst] = (int32_t)p;
+    }
+}
+
+inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
+
+inline int row_vec_ok(const float* x, int64_t ld) { return (tst_aligned16(x) && ld % 4 == 0) ? 1 : 0; }
+
+template <int K>
+int launch_topk(const float* logits, int64_t ld, int64_t R, int64_t V, float* tv, int32_t* ti, float* lse, hipStream_t st) {
+    const int vec_ok = row_vec_ok(logits, ld);
+    if (V <= 256 * MAXC * 4)
+        hipLaunchKernelGGL((logsoftmax_topk_kernel<K, true>), dim3((unsigned)R), dim3(256), 0, st, logits, ld, (int)V, tv, ti,
+                           lse, vec_ok);
+    else
+        hipLaunchKernelGGL((logsoftmax_topk_kernel<K, false>), dim3((unsigned)R), dim3(256), 0, st, logits, ld, (int)V, tv,
+                           ti, lse, vec_ok);
+    return tst_after_launch("tst_logsoftmax_topk_f32");
+}
+
+bool rows_ok(const tst_rows* r, bool need_anc) {
+    return r && r->hist && r->sent && r->tok && r->score && r->fin && r->nemit && (!need_anc || r->anc);
+}
+
+}  // namespace
+
+extern "C" int tst_argmax_rows_f32(const float* logits, int64_t ld, int64_t R, int64_t V, int32_t* tok, void* stream) {
+    TST_REQUIRE(logits && tok, TST_ERR_ARG, "tst_argmax_rows_f32: null pointer");
+    TST_REQUIRE(R >= 0 && V > 0 && ld >= V && V < (1ll << 30) && R < (1ll << 31), TST_ERR_ARG, "tst_argmax_rows_f32: bad sizes");
+    if (R == 0) return TST_OK;
+    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, ld, (int)V, tok,
+                       row_vec_ok(logits, ld));
+    return tst_after_launch("tst_argmax_rows_f32");
+}
+
+extern "C" int tst_logsoftmax_topk_f32(const float* logits, int64_t ld, int64_t R, int64_t V, int64_t k, float* top_val,
+                                       int32_t* top_idx, float* lse, void* stream) {
+    TST_REQUIRE(logits && top_val && top_idx && lse, TST_ERR_ARG, "tst_logsoftmax_topk_f32: null pointer");
+    TST_REQUIRE(R >= 0 && V > 0 && ld >= V && V < (1ll << 30) && R < (1ll << 31), TST_ERR_ARG,
+                "tst_logsoftmax_topk_f32: bad sizes");
+    TST_REQUIRE(k >= 1 && k <= 8 && k <= V, TST_ERR_UNSUPPORTED, "tst_logsoftmax_topk_f32: need 1 <= k <= min(8, V)");
+    if (R == 0) return TST_OK;
+    hipStream_t st = (hipStream_t)stream;
+    switch (k) {
+        case 1: return launch_topk<1>(logits, ld, R, V, top_val, top_idx, lse, st);
+        case 2: return launch_topk<2>(logits, ld, R, V, top_val, top_idx, lse, st);
+        case 3: return launch_topk<3>(logits, ld, R, V, top_val, top_idx, lse, st);
+        case 4: return launch_topk<4>(logits, ld, R, V, top_val, top_idx, lse, st);
+        case 5: return launch_topk<5>(logits, ld, R, V, top_val, top_idx, lse, st);
+        case 6: return launch_topk<6>(logits, ld, R, V, top_val, top_idx, lse, st);
+        case 7: return launch_topk<7>(logits, ld, R, V, top_val, top_idx, lse, st);
+        default: return launch_topk<8>(logits, ld, R, V, top_val, top_idx, lse, st);
+    }
+}
+
+extern "C" int tst_greedy_select(const int32_t* argmax_tok, int64_t n_rows, int32_t eos, int32_t* sel_parent,
+                                 int32_t* sel_tok, float* sel_score, int32_t* sel_fin, int32_t* sel_nemit,
+                                 const tst_rows* cur, void* stream) {
+    TST_REQUIRE(argmax_tok && sel_parent && sel_tok && sel_score && sel_fin && sel_nemit && rows_ok(cur, false), TST_ERR_ARG,
+                "tst_greedy_select: null pointer");
+    TST_REQUIRE(n_rows >= 0, TST_ERR_ARG, "tst_greedy_select: bad size");
+    if (n_rows == 0) return TST_OK;
+    hipLaunchKernelGGL(greedy_select_kernel, dim3(blocks_for(n_rows, 256)), dim3(256), 0, (hipStream_t)stream, argmax_tok,
+                       n_rows, eos, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, *cur);
+    return tst_after_launch("tst_greedy_select");
+}
+
+extern "C" int tst_beam_merge(const tst_rows* cur, const float* top_val, const int32_t* top_idx, const float* lse,
+                              int64_t n_sent, int64_t k, int64_t step, int32_t eos, int32_t* sel_parent, int32_t* sel_tok,
+                              float* sel_score, int32_t* sel_fin, int32_t* sel_nemit, void* stream) {
+    TST_REQUIRE(rows_ok(cur, false) && top_val && top_idx && lse && sel_parent && sel_tok && sel_score && sel_fin &&
+                    sel_nemit, TST_ERR_ARG, "tst_beam_merge: null pointer");
+    TST_REQUIRE(n_sent >= 0 && k >= 1 && k <= 8 && step >= 0, TST_ERR_ARG, "tst_beam_merge: need 1 <= k <= 8");
+    if (n_sent == 0) return TST_OK;
+    hipLaunchKernelGGL(beam_merge_kernel, dim3(blocks_for(n_sent, 256)), dim3(256), 0, (hipStream_t)stream, *cur, top_val,
+                       top_idx, lse, n_sent, (int)k, (int)step, eos, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit);
+    return tst_after_launch("tst_beam_merge");
+}
+
+extern "C" int tst_retire_compact(const tst_rows* cur, const tst_rows* nxt, const int32_t* sel_parent,
+                                  const int32_t* sel_tok, const float* sel_score, const int32_t* sel_fin,
+                                  const int32_t* sel_nemit, const float* lp, int64_t n_sent, int64_t k, int64_t step,
+                                  int64_t T, int32_t eos, int last_step, int32_t* out_tok, int32_t* out_len,
+                                  float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent, int32_t* n_alive,
+                                  void* stream) {
+    (void)eos;
+    TST_REQUIRE(rows_ok(cur, false) && rows_ok(nxt, cur && cur->anc) && sel_parent && sel_tok && sel_score && sel_fin &&
+                    sel_nemit && lp && out_tok && out_len && out_score && scratch_alive_pos && row_parent && n_alive,
+                TST_ERR_ARG, "tst_retire_compact: null pointer");
+    TST_REQUIRE(n_sent >= 0 && k >= 1 && k <= 8 && step >= 0 && step < T && n_sent * k < (1ll << 31), TST_ERR_ARG,
+                "tst_retire_compact: bad sizes (need 0 <= step < T, 1 <= k <= 8)");
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* alive = scratch_alive_pos;
+    int32_t* pos = scratch_alive_pos + n_sent;
+    if (n_sent > 0) {
+        hipLaunchKernelGGL(finish_kernel, dim3(blocks_for(n_sent, 256)), dim3(256), 0, st, *cur, sel_parent, sel_tok,
+                           sel_score, sel_fin, sel_nemit, lp, n_sent, (int)k, (int)T, last_step, out_tok, out_len, out_score,
+                           alive);
+    }
+    hipLaunchKernelGGL(scan_alive_kernel, dim3(1), dim3(1024), 0, st, alive, pos, n_sent, n_alive);
+    if (n_sent > 0) {
+        hipLaunchKernelGGL(gather_state_kernel, dim3(blocks_for(n_sent * k, 4)), dim3(256), 0, st, *cur, *nxt, sel_parent,
+                           sel_tok, sel_score, sel_fin, sel_nemit, alive, pos, n_sent * k, (int)k, (int)step, (int)T,
+                           row_parent);
+    }
+    return tst_after_launch("tst_retire_compact");
+}

@@ -1,0 +1,101 @@
+// Shared definitions of the gfx950 kernels: error reporting, wave helpers and the canonical fp32
+// functions (fixed polynomials; only +, *, fma, /, rint and bit operations, so that a CPU
+// implementation of the same formulas gives the same bits).  Compile with -ffp-contract=off.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "../../include/tst_hip.h"
+
+void tst_set_error(const char* fmt, ...);
+
+#define TST_REQUIRE(cond, code, ...)                 \
+    do {                                             \
+        if (!(cond)) {                               \
+            tst_set_error(__VA_ARGS__);              \
+            return (code);                           \
+        }                                            \
+    } while (0)
+
+static inline int tst_after_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        tst_set_error("%s: %s", what, hipGetErrorString(e));
+        return TST_ERR_LAUNCH;
+    }
+    return TST_OK;
+}
+
+static inline bool tst_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define TST_WAVE 64
+
+// sum over the 64 lanes of a wave: for off = 32,16,..,1: v = v + v(lane ^ off); every lane gets the total
+__device__ __forceinline__ float wave_sum_butterfly(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    return v;
+}
+
+// the same within aligned groups of 16 lanes (off = 8,4,2,1)
+__device__ __forceinline__ float group16_sum_butterfly(float v) {
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+__device__ __forceinline__ float d_exp(float x) {
+    if (!(x >= -87.0f)) return 0.0f;
+    if (x > 88.0f) x = 88.0f;
+    float n = rintf(x * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+    r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
+    float p = 1.9875691500e-4f;
+    p = __builtin_fmaf(p, r, 1.3981999507e-3f);
+    p = __builtin_fmaf(p, r, 8.3334519073e-3f);
+    p = __builtin_fmaf(p, r, 4.1665795894e-2f);
+    p = __builtin_fmaf(p, r, 1.6666665459e-1f);
+    p = __builtin_fmaf(p, r, 5.0000001201e-1f);
+    float r2 = r * r;
+    float y = __builtin_fmaf(p, r2, r) + 1.0f;
+    return y * __uint_as_float((uint32_t)((int)n + 127) << 23);
+}
+
+__device__ __forceinline__ float d_log(float x) {
+    uint32_t u = __float_as_uint(x);
+    int e = (int)((u >> 23) & 0xffu) - 127;
+    float m = __uint_as_float((u & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356237f) { m = m * 0.5f; e += 1; }
+    float f = m - 1.0f;
+    float s = f / (2.0f + f);
+    float z = s * s;
+    float p = 0.111111111111f;
+    p = __builtin_fmaf(p, z, 0.142857142857f);
+    p = __builtin_fmaf(p, z, 0.2f);
+    p = __builtin_fmaf(p, z, 0.333333333333f);
+    p = p * z;
+    float s2 = s + s;
+    float r = __builtin_fmaf(s2, p, s2);
+    float fe = (float)e;
+    r = __builtin_fmaf(fe, 1.42860682030941723212e-6f, r);
+    return __builtin_fmaf(fe, 0.693145751953125f, r);
+}
+
+__device__ __forceinline__ float d_sigmoid(float x) {
+    if (x >= 0.0f) { float e = d_exp(-x); return 1.0f / (1.0f + e); }
+    float e = d_exp(x);
+    return e / (1.0f + e);
+}
+
+__device__ __forceinline__ float d_tanh(float x) {
+    float a = fabsf(x);
+    float t = d_exp(-2.0f * a);
+    float r = (1.0f - t) / (1.0f + t);
+    return copysignf(r, x);
+}

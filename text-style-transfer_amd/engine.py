@@ -1,0 +1,89 @@
+"""Device-resident decode loop: greedy and beam search over a step-wise model session.
+
+Mirrors the data flow of ``InferenceState.inference`` (``/root/reference/src/inference.py:154-167``):
+one model step per generated token, selection of the next token, retirement of sentences that emitted
+EOS (stored BOS-led and EOS-stripped, ``:94-100``), compaction of the batch (``:102-120``) and storing
+of the unfinished rows after ``max_len`` steps (``:65-69``) — with all bookkeeping in HIP kernels and one
+4-byte device-to-host read per step (the number of sentences still alive).
+
+A *session* provides:
+  ``V``               vocabulary size
+  ``needs_anc``       whether it reads the ancestor table (incremental KV cache)
+  ``step(rows, n_rows, t) -> logits``   fp32 GPU tensor [>= n_rows, >= V], unit inner stride
+  ``reorder(row_parent, n_rows, identity)``  called after each step with the old row of every new row
+"""
+import torch
+
+from . import kernels as K
+
+
+def length_penalty_table(max_len, alpha):
+    """lp[n] = ((5 + n) / 6) ** alpha for n emitted tokens, as fp32 (all ones for alpha == 0)."""
+    return torch.tensor([((5.0 + n) / 6.0) ** alpha for n in range(max_len + 2)], dtype=torch.float32)
+
+
+class DecodeLoop:
+    def __init__(self, session, n_sent, beam, max_len, bos, eos, pad, alpha=0.0, device=None):
+        if not (1 <= beam <= 8):
+            raise ValueError('beam_size must be in 1..8')
+        if beam > session.V:
+            raise ValueError('beam_size larger than the vocabulary')
+        self.s, self.B, self.k, self.T = session, n_sent, beam, max_len
+        self.bos, self.eos = int(bos), int(eos)
+        dev = device or torch.device('cuda', torch.cuda.current_device())
+        self.dev = dev
+        R = n_sent * beam
+        self.cur = K.RowState(R, max_len, dev, session.needs_anc, pad)
+        self.nxt = K.RowState(R, max_len, dev, session.needs_anc, pad)
+        self.sel = K.Selection(R, dev)
+        self.cur.hist[:, 0] = self.bos
+        self.cur.tok.fill_(self.bos)
+        self.cur.sent.copy_(torch.arange(n_sent, dtype=torch.int32, device=dev).repeat_interleave(beam))
+        if beam > 1:
+            self.cur.score.fill_(float('-inf'))
+            self.cur.score[::beam] = 0.0
+        self.lp = length_penalty_table(max_len, alpha).to(dev)
+        i32 = dict(dtype=torch.int32, device=dev)
+        self.out_tok = torch.full((n_sent, max_len + 1), pad, **i32)
+        self.out_len = torch.zeros(n_sent, **i32)
+        self.out_score = torch.zeros(n_sent, dtype=torch.float32, device=dev)
+        self.scratch = torch.zeros(2 * n_sent, **i32)
+        self.row_parent = torch.zeros(R, **i32)
+        self.n_alive = torch.zeros(1, **i32)
+        self.am = torch.zeros(R, **i32)
+        if beam > 1:
+            self.top_val = torch.zeros((R, beam), dtype=torch.float32, device=dev)
+            self.top_idx = torch.zeros((R, beam), **i32)
+            self.lse = torch.zeros(R, dtype=torch.float32, device=dev)
+        self.steps_done = 0
+        self.rows_stepped = 0
+
+    def run(self, keep_logits=0):
+        """Runs the loop.  Returns (out_tok [B, T+1], out_len [B], out_score [B]) on the device; with
+        ``keep_logits`` > 0 also records (logits, sentence ids of the rows) of the first steps in
+        ``self.kept`` (a debugging aid for the fp32 tolerance checks)."""
+        s, k, T = self.s, self.k, self.T
+        n_sent = self.B
+        self.kept = []
+        for t in range(T):
+            R = n_sent * k
+            logits = s.step(self.cur, R, t)
+            if t < keep_logits:
+                self.kept.append((logits[:R, :s.V].clone(), self.cur.sent[:R].clone(), self.cur.fin[:R].clone()))
+            if k == 1:
+                K.argmax_rows(logits, R, s.V, self.am)
+                K.greedy_select(self.am, R, self.eos, self.sel, self.cur)
+            else:
+                K.logsoftmax_topk(logits, R, s.V, k, self.top_val, self.top_idx, self.lse)
+                K.beam_merge(self.cur, self.top_val, self.top_idx, self.lse, n_sent, k, t, self.eos, self.sel)
+            K.retire_compact(self.cur, self.nxt, self.sel, self.lp, n_sent, k, t, T, self.eos, t == T - 1, self.out_tok,
+                             self.out_len, self.out_score, self.scratch, self.row_parent, self.n_alive)
+            self.cur, self.nxt = self.nxt, self.cur
+            self.steps_done += 1
+            self.rows_stepped += R
+            alive = int(self.n_alive.item())  # the one host read of the step
+            if alive == 0:
+                break
+            s.reorder(self.row_parent, alive * k, identity=(k == 1 and alive == n_sent))
+            n_sent = alive
+        return self.out_tok, self.out_len, self.out_score

@@ -1,0 +1,151 @@
+"""``InferenceState`` / ``simple_inference`` with the call surface of ``/root/reference/src/inference.py``.
+
+Same constructor dict and defaults (``:12-45``), same checks (``:50-58``), same results: a list, in
+original batch order, of 1-D id tensors that start with BOS and do not contain EOS, cut after
+``max_len`` generated tokens (``:94-100``, ``:65-69``, ``:154-167``).  What differs is where the work
+happens: token selection, EOS retirement, batch compaction and the hypothesis bookkeeping run in HIP
+kernels on device-resident state (``engine.DecodeLoop``), and models of this package are stepped
+incrementally (KV cache / carried GRU state) instead of being re-run on the whole prefix (``:132``).
+
+Additive keys (not in the reference): ``beam_size`` (1 = the reference's greedy arg-max; the reference
+has no beam search), ``length_penalty`` (alpha of ((5 + n) / 6) ** alpha, used to rank finished beams).
+
+Any other callable works as ``model`` too (the reference's protocol ``model(inputs, active_seqs, *args,
+**kwargs) -> [B, t, V]`` or ``(logits, new_inputs)`` with ``substitute_inputs``); it is then called once
+per step exactly as the reference does, on GPU tensors, and only the selection / bookkeeping is ours.
+"""
+import torch
+
+from .engine import DecodeLoop
+
+
+class ForeignSession:
+    """Steps an arbitrary model callable with the reference's protocol (``/root/reference/src/inference.py:122-132``)."""
+    needs_anc = False
+
+    def __init__(self, model, inputs, enc_mask, kwargs, substitute_inputs, inputs_batch_dim, beam, vocab_size):
+        if inputs_batch_dim not in (0, 1, 2):
+            raise NotImplementedError  # as /root/reference/src/inference.py:117
+        self.model, self.kwargs, self.sub, self.dim = model, kwargs, substitute_inputs, inputs_batch_dim
+        self.inputs = inputs if beam == 1 else inputs.repeat_interleave(beam, dim=inputs_batch_dim)
+        self.enc_mask = enc_mask if (enc_mask is None or beam == 1) else enc_mask.repeat_interleave(beam, dim=0)
+        self.V = vocab_size
+
+    def step(self, rows, n, t):
+        active = rows.hist[:n, :t + 1].long()
+        args = [] if self.enc_mask is None else self.enc_mask
+        with torch.no_grad():
+            if self.sub:
+                out, self.inputs = self.model(self.inputs, active[:, t:], *args, **self.kwargs)
+            else:
+                out = self.model(self.inputs, active, *args, **self.kwargs)
+        logits = out[:, -1]
+        if logits.shape[-1] != self.V:
+            raise ValueError('model returned %d classes, vocabulary has %d' % (logits.shape[-1], self.V))
+        return logits.to(torch.float32).contiguous()
+
+    def reorder(self, row_parent, n_rows, identity):
+        if identity:
+            return
+        idx = row_parent[:n_rows].long()
+        self.inputs = self.inputs.index_select(self.dim, idx)
+        if self.enc_mask is not None:
+            self.enc_mask = self.enc_mask.index_select(0, idx)
+
+
+class InferenceState:
+    def __init__(self, state_dict: dict):
+        # Required arguments (/root/reference/src/inference.py:14-16)
+        self.model = state_dict['model']
+        self.vocab = state_dict['vocab']
+        self.inputs = state_dict['inputs']
+
+        # Optional arguments, same defaults (/root/reference/src/inference.py:19-37)
+        self.bos_token = state_dict.get('bos_token', '<bos>')
+        self.eos_token = state_dict.get('eos_token', '<eos>')
+        self.pad_token = state_dict.get('pad_token', '<pad>')
+        self.unk_token = state_dict.get('unk_token', '<unk>')
+        self.bos_idx = self.vocab.stoi[self.bos_token]
+        self.eos_idx = self.vocab.stoi[self.eos_token]
+        self.pad_idx = self.vocab.stoi[self.pad_token]
+        self.unk_idx = self.vocab.stoi[self.unk_token]
+        self.max_len = state_dict.get('max_len', 100)
+        self.temperature = state_dict.get('temperature', 1)
+        self.sample_type = state_dict.get('sample_type', 'max')
+        self.kwargs = state_dict.get('kwargs', {})
+        self.gumbel = state_dict.get('gumbel', False)
+        self.enc_mask = state_dict.get('enc_mask')
+        self.should_stack_finished = state_dict.get('should_stack_finished', False)
+        self.inputs_batch_dim = state_dict.get('inputs_batch_dim', 0)
+        self.substitute_inputs = state_dict.get('substitute_inputs', False)
+        self.batch_size = self.inputs.size(self.inputs_batch_dim)
+        self.active_seqs = state_dict.get('active_seqs')
+
+        # Additive keys
+        self.beam_size = state_dict.get('beam_size', 1)
+        self.length_penalty = state_dict.get('length_penalty', 0.0)
+
+        self.finished = [None for _ in range(self.batch_size)]
+        self.num_steps_done = 0
+        self.validate()
+
+    def validate(self):
+        assert self.max_len > 0
+        assert self.batch_size > 0
+        assert type(self.bos_token) is str
+        assert type(self.eos_token) is str
+        # bos/eos must be in the dictionary (/root/reference/src/inference.py:56-58)
+        assert self.bos_idx != self.vocab.stoi[self.unk_token]
+        assert self.eos_idx != self.vocab.stoi[self.unk_token]
+
+    def _session(self):
+        if hasattr(self.model, 'session') and not self.kwargs.get('force_foreign', False):
+            return self.model.session(self.inputs, self.enc_mask, self.beam_size, self.max_len)
+        kwargs = {k: v for k, v in self.kwargs.items() if k != 'force_foreign'}
+        return ForeignSession(self.model, self.inputs, self.enc_mask, kwargs, self.substitute_inputs,
+                              self.inputs_batch_dim, self.beam_size, len(self.vocab))
+
+    def inference(self, keep_logits=0):
+        if self.sample_type != 'max':
+            if self.sample_type == 'sample':
+                raise NotImplementedError("sample_type='sample' is not available in this build yet")
+            raise NotImplementedError  # as /root/reference/src/inference.py:149
+        if self.gumbel:
+            raise NotImplementedError('gumbel decoding is not available in this build yet')
+        if self.active_seqs is not None:
+            raise NotImplementedError('a caller-provided active_seqs prefix is not supported')
+        if not torch.cuda.is_available():
+            raise RuntimeError('InferenceState needs a GPU: the decode loop runs in HIP kernels and has no CPU path')
+        device = self.inputs.device if self.inputs.is_cuda else torch.device('cuda', torch.cuda.current_device())
+        with torch.cuda.device(device):
+            loop = DecodeLoop(self._session(), self.batch_size, self.beam_size, self.max_len, self.bos_idx,
+                              self.eos_idx, self.pad_idx, self.length_penalty, device)
+            out_tok, out_len, out_score = loop.run(keep_logits)
+            self.loop = loop
+            self.num_steps_done = loop.steps_done
+            lens = out_len.cpu().tolist()
+            toks = out_tok.long()
+            self.scores = out_score
+            self.finished = [toks[i, :n] for i, n in enumerate(lens)]
+        if self.should_stack_finished:
+            self.stack_finished()
+        return self.finished
+
+    def stack_finished(self):
+        """Pads with ``<pad>`` and stacks (``/root/reference/src/inference.py:71-92``).  The reference builds its
+        pads as float zeros, so the stacked tensor is float32 under type promotion; kept for parity."""
+        width = max(len(s) for s in self.finished)
+        rows = []
+        for s in self.finished:
+            pads = torch.zeros(width - len(s), device=s.device).fill_(self.pad_idx)
+            rows.append(s if len(s) == width else torch.cat((s, pads), dim=0))
+        self.finished = torch.stack(rows)
+
+
+def simple_inference(model, z, vocab, max_len=100, eos_token='<eos>'):
+    """``/root/reference/src/inference.py:170-181``: greedy decode, result as ``list[list[int]]``."""
+    state = InferenceState({'model': model, 'inputs': z, 'vocab': vocab, 'max_len': max_len, 'eos_token': eos_token})
+    state.inference()
+    lens = state.loop.out_len.cpu().tolist()
+    toks = state.loop.out_tok.cpu().tolist()
+    return [row[:n] for row, n in zip(toks, lens)]

@@ -1,0 +1,147 @@
+"""Thin wrappers that launch the HIP kernels of ``libtst_hip.so`` on torch device tensors.
+
+torch is used for device memory and the current stream only; every function below is one C-ABI call.
+Tensors must be contiguous fp32 / int32 on the GPU; outputs are written into caller-provided tensors.
+"""
+import torch
+
+from . import _lib
+from ._lib import call
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _chk(t, dtype, name):
+    if t is None:
+        return
+    if not (t.is_cuda and t.dtype == dtype and t.is_contiguous()):
+        raise ValueError('%s must be a contiguous %s tensor on the GPU (got %s, %s, cuda=%s)'
+                         % (name, dtype, t.dtype, tuple(t.shape), t.is_cuda))
+
+
+def embed_posadd(tok, emb, pe, scale, out, n_rows, pos=None):
+    """out[:n_rows] = emb[tok[:n_rows]] * scale + (pe[pos[r]] if pos is given else the single row pe)"""
+    _chk(tok, torch.int32, 'tok'); _chk(emb, torch.float32, 'emb'); _chk(pe, torch.float32, 'pe')
+    _chk(out, torch.float32, 'out'); _chk(pos, torch.int32, 'pos')
+    V, d = emb.shape
+    assert out.shape[1] == d and out.shape[0] >= n_rows and tok.shape[0] >= n_rows
+    call('tst_embed_posadd_f32', _p(tok), _p(emb), _p(pe), _p(pos), float(scale), _p(out), n_rows, d, V, _stream())
+
+
+def layernorm(x, gamma, beta, out, n_rows, eps=1e-5):
+    _chk(x, torch.float32, 'x'); _chk(out, torch.float32, 'out'); _chk(gamma, torch.float32, 'gamma'); _chk(beta, torch.float32, 'beta')
+    d = x.shape[1]
+    assert gamma.numel() == d and beta.numel() == d and out.shape[1] == d
+    call('tst_layernorm_f32', _p(x), _p(gamma), _p(beta), float(eps), _p(out), n_rows, d, _stream())
+
+
+def gemm(a, wt, bias, out, n_rows, n_cols=None, res=None, act=0):
+    """out[:n_rows, :N] = epilogue(a[:n_rows] @ wt[:, :N] + bias); ``wt`` is [K, ldw] with ldw >= N.
+    ``a``, ``out`` and ``res`` may be row-strided 2-D views (unit stride in the last dimension)."""
+    for t, nm in ((a, 'a'), (wt, 'wt'), (out, 'out'), (res, 'res'), (bias, 'bias')):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1):
+            raise ValueError('%s must be an fp32 GPU tensor with unit inner stride' % nm)
+    K, ldw = wt.shape[0], wt.stride(0)
+    N = wt.shape[1] if n_cols is None else n_cols
+    assert a.shape[1] == K and out.shape[1] >= N and a.shape[0] >= n_rows and out.shape[0] >= n_rows
+    assert bias is None or bias.numel() >= N
+    call('tst_gemm_mfma_f32', _p(a), a.stride(0), _p(wt), ldw, _p(bias), _p(res), 0 if res is None else res.stride(0),
+         _p(out), out.stride(0), n_rows, N, K, int(act), _stream())
+
+
+def attn_self_step(cache, anc, pos, out, n_rows, d, heads):
+    """cache [n_pos, slab_rows, 3d]; anc [rows, T] int32"""
+    _chk(cache, torch.float32, 'cache'); _chk(anc, torch.int32, 'anc'); _chk(out, torch.float32, 'out')
+    assert cache.shape[2] == 3 * d and pos < cache.shape[0] and out.shape[1] == d
+    call('tst_attn_self_step_f32', _p(cache), cache.shape[1], _p(anc), anc.shape[1], pos, _p(out), n_rows, d, heads, _stream())
+
+
+def attn_cross_step(q, kv, mask, sent, out, n_rows, d, heads):
+    """q [rows, d]; kv [n_sent, S, 2d]; mask [n_sent, S] uint8 or None; sent [rows] int32"""
+    _chk(q, torch.float32, 'q'); _chk(kv, torch.float32, 'kv'); _chk(mask, torch.uint8, 'mask'); _chk(sent, torch.int32, 'sent')
+    _chk(out, torch.float32, 'out')
+    assert kv.shape[2] == 2 * d and (mask is None or tuple(mask.shape) == tuple(kv.shape[:2]))
+    call('tst_attn_cross_step_f32', _p(q), _p(kv), _p(mask), _p(sent), kv.shape[1], _p(out), n_rows, d, heads, _stream())
+
+
+def gru_cell_step(gi, gh, h, h_out, n_rows):
+    for t, nm in ((gi, 'gi'), (gh, 'gh'), (h, 'h'), (h_out, 'h_out')):
+        _chk(t, torch.float32, nm)
+    H = h.shape[1]
+    assert gi.shape[1] == 3 * H and gh.shape[1] == 3 * H
+    call('tst_gru_cell_step_f32', _p(gi), _p(gh), _p(h), _p(h_out), n_rows, H, _stream())
+
+
+def gather_rows(src, idx, dst, n_rows):
+    _chk(src, torch.float32, 'src'); _chk(dst, torch.float32, 'dst'); _chk(idx, torch.int32, 'idx')
+    assert src.shape[1] == dst.shape[1]
+    call('tst_gather_rows_f32', _p(src), _p(idx), _p(dst), n_rows, src.shape[1], _stream())
+
+
+def argmax_rows(logits, n_rows, n_cols, out_tok):
+    _chk(out_tok, torch.int32, 'out_tok')
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.stride(-1) == 1
+    call('tst_argmax_rows_f32', _p(logits), logits.stride(0), n_rows, n_cols, _p(out_tok), _stream())
+
+
+def logsoftmax_topk(logits, n_rows, n_cols, k, top_val, top_idx, lse):
+    _chk(top_val, torch.float32, 'top_val'); _chk(top_idx, torch.int32, 'top_idx'); _chk(lse, torch.float32, 'lse')
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.stride(-1) == 1
+    call('tst_logsoftmax_topk_f32', _p(logits), logits.stride(0), n_rows, n_cols, k, _p(top_val), _p(top_idx), _p(lse),
+         _stream())
+
+
+class RowState:
+    """Per-row decode state on the device (``tst_rows``): token history, ancestor table, scores, flags."""
+
+    def __init__(self, rows, T, device, with_anc, fill_token):
+        i32 = dict(dtype=torch.int32, device=device)
+        self.hist = torch.full((rows, T + 1), fill_token, **i32)
+        self.anc = torch.zeros((rows, T), **i32) if with_anc else None
+        self.sent = torch.zeros(rows, **i32)
+        self.tok = torch.zeros(rows, **i32)
+        self.score = torch.zeros(rows, dtype=torch.float32, device=device)
+        self.fin = torch.zeros(rows, **i32)
+        self.nemit = torch.zeros(rows, **i32)
+
+    def struct(self):
+        return _lib.TstRows(_p(self.hist), _p(self.anc), _p(self.sent), _p(self.tok), _p(self.score), _p(self.fin),
+                            _p(self.nemit))
+
+
+class Selection:
+    """Output arrays of the select kernels (one entry per new row slot)."""
+
+    def __init__(self, rows, device):
+        i32 = dict(dtype=torch.int32, device=device)
+        self.parent = torch.zeros(rows, **i32)
+        self.tok = torch.zeros(rows, **i32)
+        self.score = torch.zeros(rows, dtype=torch.float32, device=device)
+        self.fin = torch.zeros(rows, **i32)
+        self.nemit = torch.zeros(rows, **i32)
+
+    def ptrs(self):
+        return _p(self.parent), _p(self.tok), _p(self.score), _p(self.fin), _p(self.nemit)
+
+
+def greedy_select(argmax_tok, n_rows, eos, sel, cur):
+    st = cur.struct()
+    call('tst_greedy_select', _p(argmax_tok), n_rows, eos, *sel.ptrs(), st, _stream())
+
+
+def beam_merge(cur, top_val, top_idx, lse, n_sent, k, step, eos, sel):
+    st = cur.struct()
+    call('tst_beam_merge', st, _p(top_val), _p(top_idx), _p(lse), n_sent, k, step, eos, *sel.ptrs(), _stream())
+
+
+def retire_compact(cur, nxt, sel, lp, n_sent, k, step, T, eos, last_step, out_tok, out_len, out_score, scratch, row_parent,
+                   n_alive):
+    a, b = cur.struct(), nxt.struct()
+    call('tst_retire_compact', a, b, *sel.ptrs(), _p(lp), n_sent, k, step, T, eos, int(last_step), _p(out_tok), _p(out_len),
+         _p(out_score), _p(scratch), _p(row_parent), _p(n_alive), _stream())

@@ -1,0 +1,123 @@
+"""GRU decoder / language model whose decode steps run on the HIP kernels.
+
+Call surfaces as used by the reference: ``RNNDecoder(emb_size, hid_size, vocab, dropword_p)`` with
+``decoder(z [B,H], x [B,T]) -> [B,T,V]`` (``/root/reference/src/trainers/cyclegan_trainer.py:64``,
+``/root/reference/src/inference.py:170-177``) and ``RNNLM(size, vocab, n_layers)`` with
+``lm(z [n_layers,B,H], x, return_z=True) -> (logits, z')`` (``/root/reference/src/prod/dialog_model.py:49,108-120``).
+Architecture (this build's own, the reference's model source is an absent submodule): embedding ->
+n_layers GRU (PyTorch gate order and formula) -> linear to raw logits.  The decode loop carries the hidden
+state instead of re-running the prefix (``/root/reference/src/inference.py:132`` re-runs it).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import kernels as K
+from .transformer import HipModule, _t
+
+
+class _GRUModel(HipModule):
+    def __init__(self, emb_size, hid_size, vocab, n_layers, device):
+        super().__init__(device)
+        self.vocab = vocab
+        self.E, self.H, self.V, self.n_layers = emb_size, hid_size, len(vocab), n_layers
+        if emb_size % 4 or hid_size % 4:
+            raise ValueError('embedding and hidden sizes must be multiples of 4')
+        s = 1.0 / math.sqrt(hid_size)
+        self._add('embed.weight', (self.V, emb_size), std=1.0)
+        for l in range(n_layers):
+            inp = emb_size if l == 0 else hid_size
+            self._add('gru.weight_ih_l%d' % l, (3 * hid_size, inp), std=s)
+            self._add('gru.weight_hh_l%d' % l, (3 * hid_size, hid_size), std=s)
+            self._add('gru.bias_ih_l%d' % l, (3 * hid_size,), std=s)
+            self._add('gru.bias_hh_l%d' % l, (3 * hid_size,), std=s)
+        self._add('out.weight', (self.V, hid_size), std=s)
+        self._add('out.bias', (self.V,), fill=0.0)
+
+    def prepared(self):
+        if self._prepared is None:
+            P, W = self._params, {}
+            W['emb'] = P['embed.weight'].contiguous()
+            W['cells'] = [dict(wih=_t(P['gru.weight_ih_l%d' % l]), bih=P['gru.bias_ih_l%d' % l],
+                               whh=_t(P['gru.weight_hh_l%d' % l]), bhh=P['gru.bias_hh_l%d' % l])
+                          for l in range(self.n_layers)]
+            W['wout'], W['bout'] = _t(P['out.weight']), P['out.bias']
+            self._prepared = W
+        return self._prepared
+
+    def session(self, z, enc_mask=None, rows_per_sentence=1, max_len=None):
+        return GRUSession(self, z, rows_per_sentence)
+
+    def _run_prefix(self, z, x):
+        """Teacher-forced evaluation: logits [B,T,V] and the final state [n_layers,B,H]."""
+        B, T = x.shape
+        sess = GRUSession(self, z, 1)
+        rows = K.RowState(B, max(T, 1), self.device, False, 0)
+        out = torch.empty((B, T, self.V), dtype=torch.float32, device=self.device)
+        x32 = x.to(device=self.device, dtype=torch.int32)
+        for p in range(T):
+            rows.tok.copy_(x32[:, p])
+            out[:, p] = sess.step(rows, B, p)[:B, :self.V]
+        return out, torch.stack([h[:B].clone() for h in sess.h])
+
+
+class RNNDecoder(_GRUModel):
+    def __init__(self, emb_size, hid_size, vocab, dropword_p=0.0, device='cuda'):
+        super().__init__(emb_size, hid_size, vocab, 1, device)
+
+    def __call__(self, z, x):
+        return self._run_prefix(z, x)[0]
+
+
+class RNNLM(_GRUModel):
+    def __init__(self, size, vocab, n_layers=1, device='cuda'):
+        super().__init__(size, size, vocab, n_layers, device)
+
+    def __call__(self, z, x, return_z=False):
+        logits, z_new = self._run_prefix(z, x)
+        return (logits, z_new) if return_z else logits
+
+
+class GRUSession:
+    """Carried hidden state [layer][row][H] (two buffers per layer: rows are re-gathered when the batch
+    is compacted or beams are reordered) and work buffers."""
+    needs_anc = False
+
+    def __init__(self, model, z, k):
+        self.m, self.V = model, model.V
+        dev = model.device
+        z = z.to(device=dev, dtype=torch.float32)
+        if z.dim() == 2:
+            z = z.unsqueeze(0)
+        if z.shape[0] != model.n_layers or z.shape[2] != model.H:
+            raise ValueError('state must be [n_layers=%d, B, H=%d], got %s' % (model.n_layers, model.H, tuple(z.shape)))
+        B = z.shape[1]
+        R = B * k
+        self.R = R
+        self.h = [z[l].repeat_interleave(k, dim=0).contiguous() for l in range(model.n_layers)]
+        f32 = dict(dtype=torch.float32, device=dev)
+        self.h_alt = [torch.empty((R, model.H), **f32) for _ in range(model.n_layers)]
+        self.x = torch.empty((R, model.E), **f32)
+        self.gi = torch.empty((R, 3 * model.H), **f32)
+        self.gh = torch.empty((R, 3 * model.H), **f32)
+        self.logits = torch.empty((R, (model.V + 3) // 4 * 4), **f32)
+
+    def reorder(self, row_parent, n_rows, identity):
+        if identity:
+            return
+        for l in range(len(self.h)):
+            K.gather_rows(self.h[l], row_parent, self.h_alt[l], n_rows)
+            self.h[l], self.h_alt[l] = self.h_alt[l], self.h[l]
+
+    def step(self, rows, n, t):
+        m, W = self.m, self.m.prepared()
+        K.embed_posadd(rows.tok, W['emb'], None, 1.0, self.x, n)
+        x = self.x
+        for l, c in enumerate(W['cells']):
+            K.gemm(x, c['wih'], c['bih'], self.gi, n)
+            K.gemm(self.h[l], c['whh'], c['bhh'], self.gh, n)
+            K.gru_cell_step(self.gi, self.gh, self.h[l], self.h[l], n)
+            x = self.h[l]
+        K.gemm(x, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
+        return self.logits

@@ -1,0 +1,288 @@
+"""Transformer encoder-decoder whose decode steps run on the HIP kernels.
+
+Call surface as used by the reference (``/root/reference/src/trainers/transformer_mt_trainer.py:55,91-98``):
+``Transformer(hp.transformer, vocab_src, vocab_trg)``, ``.encoder(src) -> (encs, enc_mask)``,
+``.decoder(encs, ys, *enc_mask) -> [B, t, V]`` raw logits; ``hp`` carries ``d_model, n_layers, n_heads, d_ff,
+pe_max_len, dropout`` (``/root/reference/experiments/transformer-mt/config.yml:21-27``).  The model source
+of the reference is an absent submodule; the architecture is this build's own: pre-norm layers, sinusoidal
+positions added to ``embedding * sqrt(d_model)``, final LayerNorm, linear output to raw logits.
+
+Parameters are fp32 torch tensors on the GPU, named like an ``nn.Module`` of the same structure so that
+``state_dict()`` / ``load_state_dict()`` interchange with ordinary checkpoints.  For the kernels the
+weights are re-laid once: every ``nn.Linear`` weight transposed to [in, out] (the GEMM streams it along
+``out``), q|k|v of self-attention fused to one [d, 3d] matrix, k|v of cross-attention to [d, 2d].
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import kernels as K
+
+
+class HP(dict):
+    """Attribute-access dict (the shape of a firelab config node)."""
+    __getattr__ = dict.__getitem__
+
+
+def sinusoid_table(n_pos, d_model):
+    pos = torch.arange(n_pos, dtype=torch.float64).unsqueeze(1)
+    div = torch.exp(torch.arange(0, d_model, 2, dtype=torch.float64) * (-math.log(10000.0) / d_model))
+    pe = torch.zeros(n_pos, d_model, dtype=torch.float64)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe.to(torch.float32)
+
+
+class HipModule:
+    """Minimal parameter container with the ``nn.Module`` methods the reference's callers use."""
+
+    def __init__(self, device):
+        self.device = torch.device(device)
+        self._params = OrderedDict()
+        self._prepared = None
+
+    def _add(self, name, shape, std=None, fill=None):
+        if fill is not None:
+            t = torch.full(shape, float(fill), dtype=torch.float32)
+        else:
+            t = torch.randn(shape, dtype=torch.float32) * std
+        self._params[name] = t.to(self.device)
+
+    def state_dict(self):
+        return OrderedDict((k, v.clone()) for k, v in self._params.items())
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [k for k in self._params if k not in sd]
+        extra = [k for k in sd if k not in self._params]
+        if strict and (missing or extra):
+            raise KeyError('state_dict mismatch: missing %s, unexpected %s' % (missing, extra))
+        for k in self._params:
+            if k in sd:
+                if tuple(sd[k].shape) != tuple(self._params[k].shape):
+                    raise ValueError('shape mismatch for %s: %s vs %s' % (k, tuple(sd[k].shape), tuple(self._params[k].shape)))
+                self._params[k] = sd[k].detach().to(device=self.device, dtype=torch.float32).contiguous().clone()
+        self._prepared = None
+        return self
+
+    def parameters(self):
+        return list(self._params.values())
+
+    def eval(self):
+        return self
+
+    def train(self, mode=True):
+        return self
+
+    def to(self, device):
+        self.device = torch.device(device)
+        self._params = OrderedDict((k, v.to(self.device)) for k, v in self._params.items())
+        self._prepared = None
+        return self
+
+    def cuda(self):
+        return self.to('cuda')
+
+
+def _t(w):
+    """nn.Linear weight [out, in] -> [in, ld] with ld = out rounded up to a multiple of 4 (zero filled)."""
+    out_f, in_f = w.shape
+    ld = (out_f + 3) // 4 * 4
+    wt = torch.zeros((in_f, ld), dtype=torch.float32, device=w.device)
+    wt[:, :out_f] = w.t()
+    return wt[:, :out_f]
+
+
+def _normalise_mask(enc_mask, B, S, device):
+    """Accepts [B,1,S] / [B,S] bool or byte masks, or the B rows [1,S] that
+    ``/root/reference/src/inference.py:124,132`` produces by star-unpacking; returns uint8 [B,S] or None."""
+    if enc_mask is None or (isinstance(enc_mask, (tuple, list)) and len(enc_mask) == 0):
+        return None
+    if isinstance(enc_mask, (tuple, list)):
+        enc_mask = enc_mask[0] if (len(enc_mask) == 1 and enc_mask[0].dim() == 3) else torch.stack(list(enc_mask))
+    m = enc_mask.reshape(B, S)
+    return m.to(device=device, dtype=torch.uint8).contiguous()
+
+
+class TransformerDecoder(HipModule):
+    def __init__(self, hp, vocab, device='cuda'):
+        super().__init__(device)
+        hp = HP(hp)
+        self.hp, self.vocab = hp, vocab
+        d, V, ff = hp.d_model, len(vocab), hp.d_ff
+        self.d, self.V, self.heads, self.n_layers = d, V, hp.n_heads, hp.n_layers
+        if d % hp.n_heads or (d // hp.n_heads) % 4 or d % 4:
+            raise ValueError('d_model / n_heads must be a multiple of 4')
+        s = 1.0 / math.sqrt(d)
+        self._add('embed.weight', (V, d), std=s)
+        self._params['pe'] = sinusoid_table(hp.pe_max_len, d).to(self.device)
+        for i in range(hp.n_layers):
+            p = 'layers.%d.' % i
+            for ln, att in (('ln1', 'self_attn'), ('ln2', 'cross_attn')):
+                self._add(p + ln + '.weight', (d,), fill=1.0)
+                self._add(p + ln + '.bias', (d,), fill=0.0)
+                for n in 'qkvo':
+                    self._add(p + att + '.' + n + '.weight', (d, d), std=s)
+                    self._add(p + att + '.' + n + '.bias', (d,), fill=0.0)
+            self._add(p + 'ln3.weight', (d,), fill=1.0)
+            self._add(p + 'ln3.bias', (d,), fill=0.0)
+            self._add(p + 'ff.w1.weight', (ff, d), std=s)
+            self._add(p + 'ff.w1.bias', (ff,), fill=0.0)
+            self._add(p + 'ff.w2.weight', (d, ff), std=1.0 / math.sqrt(ff))
+            self._add(p + 'ff.w2.bias', (d,), fill=0.0)
+        self._add('ln.weight', (d,), fill=1.0)
+        self._add('ln.bias', (d,), fill=0.0)
+        self._add('out.weight', (V, d), std=s)
+        self._add('out.bias', (V,), fill=0.0)
+        # nn.Module orders ln1, self_attn, ln2, cross_attn, ln3, ff; keep that order for checkpoints
+        self._params = OrderedDict((k, self._params[k]) for k in self._ordered_names())
+
+    def _ordered_names(self):
+        names = ['embed.weight']
+        for i in range(self.n_layers):
+            p = 'layers.%d.' % i
+            for ln, att in (('ln1', 'self_attn'), ('ln2', 'cross_attn')):
+                names += [p + ln + '.weight', p + ln + '.bias']
+                for n in 'qkvo':
+                    names += [p + att + '.' + n + '.weight', p + att + '.' + n + '.bias']
+            names += [p + 'ln3.weight', p + 'ln3.bias', p + 'ff.w1.weight', p + 'ff.w1.bias', p + 'ff.w2.weight',
+                      p + 'ff.w2.bias']
+        return names + ['ln.weight', 'ln.bias', 'out.weight', 'out.bias', 'pe']
+
+    def prepared(self):
+        if self._prepared is None:
+            P, W = self._params, {}
+            W['emb'], W['pe'] = P['embed.weight'].contiguous(), P['pe'].contiguous()
+            W['layers'] = []
+            for i in range(self.n_layers):
+                p = 'layers.%d.' % i
+                L = {}
+                for n in ('ln1', 'ln2', 'ln3'):
+                    L[n] = (P[p + n + '.weight'], P[p + n + '.bias'])
+                sa, ca = p + 'self_attn.', p + 'cross_attn.'
+                L['wqkv'] = _t(torch.cat([P[sa + 'q.weight'], P[sa + 'k.weight'], P[sa + 'v.weight']], 0))
+                L['bqkv'] = torch.cat([P[sa + 'q.bias'], P[sa + 'k.bias'], P[sa + 'v.bias']]).contiguous()
+                L['wo'], L['bo'] = _t(P[sa + 'o.weight']), P[sa + 'o.bias']
+                L['cwq'], L['cbq'] = _t(P[ca + 'q.weight']), P[ca + 'q.bias']
+                L['cwkv'] = _t(torch.cat([P[ca + 'k.weight'], P[ca + 'v.weight']], 0))
+                L['cbkv'] = torch.cat([P[ca + 'k.bias'], P[ca + 'v.bias']]).contiguous()
+                L['cwo'], L['cbo'] = _t(P[ca + 'o.weight']), P[ca + 'o.bias']
+                L['w1'], L['b1'] = _t(P[p + 'ff.w1.weight']), P[p + 'ff.w1.bias']
+                L['w2'], L['b2'] = _t(P[p + 'ff.w2.weight']), P[p + 'ff.w2.bias']
+                W['layers'].append(L)
+            W['ln'] = (P['ln.weight'], P['ln.bias'])
+            W['wout'], W['bout'] = _t(P['out.weight']), P['out.bias']
+            self._prepared = W
+        return self._prepared
+
+    # ---- step-wise protocol used by the decode loop -------------------------------------------------
+    def session(self, encs, enc_mask, rows_per_sentence, max_len):
+        return TransformerSession(self, encs, enc_mask, rows_per_sentence, max_len)
+
+    # ---- reference call protocol: whole-prefix logits ------------------------------------------------
+    def __call__(self, encs, ys, *enc_mask):
+        """encs [B,S,d], ys [B,t] ids -> raw logits [B,t,V] (teacher forcing; every position attends to its
+        prefix).  Evaluated as t incremental steps over the KV cache."""
+        B, t = ys.shape
+        sess = self.session(encs, enc_mask, 1, t)
+        rows = K.RowState(B, t, self.device, True, 0)
+        rows.sent.copy_(torch.arange(B, dtype=torch.int32, device=self.device))
+        rows.anc.copy_(torch.arange(B, dtype=torch.int32, device=self.device).unsqueeze(1).expand(B, t))
+        out = torch.empty((B, t, self.V), dtype=torch.float32, device=self.device)
+        ys32 = ys.to(device=self.device, dtype=torch.int32)
+        for p in range(t):
+            rows.tok.copy_(ys32[:, p])
+            out[:, p] = sess.step(rows, B, p)[:B, :self.V]
+        return out
+
+
+class TransformerSession:
+    """Per-batch decode state of a ``TransformerDecoder``: cross-attention k|v of the encoder outputs
+    (computed once), the self-attention q|k|v cache [layer][position][row slot][3d] and work buffers."""
+    needs_anc = True
+
+    def __init__(self, dec, encs, enc_mask, k, max_len):
+        self.dec, self.V = dec, dec.V
+        W = dec.prepared()
+        dev = dec.device
+        if max_len > W['pe'].shape[0]:
+            raise ValueError('max_len %d exceeds pe_max_len %d' % (max_len, W['pe'].shape[0]))
+        encs = encs.to(device=dev, dtype=torch.float32).contiguous()
+        B, S, d = encs.shape
+        if d != dec.d:
+            raise ValueError('encoder width %d != d_model %d' % (d, dec.d))
+        self.B, self.S, self.k = B, S, k
+        R = B * k
+        self.R = R
+        self.mask = _normalise_mask(enc_mask, B, S, dev)
+        f32 = dict(dtype=torch.float32, device=dev)
+        flat = encs.view(B * S, d)
+        self.kv_cross = []
+        for L in W['layers']:
+            kv = torch.empty((B, S, 2 * d), **f32)
+            K.gemm(flat, L['cwkv'], L['cbkv'], kv.view(B * S, 2 * d), B * S)
+            self.kv_cross.append(kv)
+        self.cache = [torch.empty((max_len, R, 3 * d), **f32) for _ in W['layers']]
+        self.x = torch.empty((R, d), **f32)
+        self.h = torch.empty((R, d), **f32)
+        self.q = torch.empty((R, d), **f32)
+        self.a = torch.empty((R, d), **f32)
+        self.ff = torch.empty((R, dec.hp.d_ff), **f32)
+        self.logits = torch.empty((R, (dec.V + 3) // 4 * 4), **f32)
+        self.scale = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
+
+    def reorder(self, row_parent, n_rows, identity):
+        pass  # the KV cache is addressed through the ancestor table; nothing moves
+
+    def step(self, rows, n, t):
+        dec, W = self.dec, self.dec.prepared()
+        d, H = dec.d, dec.heads
+        x, h, q, a, ff = self.x, self.h, self.q, self.a, self.ff
+        K.embed_posadd(rows.tok, W['emb'], W['pe'][t], self.scale, x, n)
+        for li, L in enumerate(W['layers']):
+            K.layernorm(x, L['ln1'][0], L['ln1'][1], h, n)
+            K.gemm(h, L['wqkv'], L['bqkv'], self.cache[li][t], n)
+            K.attn_self_step(self.cache[li], rows.anc, t, a, n, d, H)
+            K.gemm(a, L['wo'], L['bo'], x, n, res=x)
+            K.layernorm(x, L['ln2'][0], L['ln2'][1], h, n)
+            K.gemm(h, L['cwq'], L['cbq'], q, n)
+            K.attn_cross_step(q, self.kv_cross[li], self.mask, rows.sent, a, n, d, H)
+            K.gemm(a, L['cwo'], L['cbo'], x, n, res=x)
+            K.layernorm(x, L['ln3'][0], L['ln3'][1], h, n)
+            K.gemm(h, L['w1'], L['b1'], ff, n, act=1)
+            K.gemm(ff, L['w2'], L['b2'], x, n, res=x)
+        K.layernorm(x, W['ln'][0], W['ln'][1], h, n)
+        K.gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
+        return self.logits
+
+
+class Transformer(HipModule):
+    """``Transformer(hp, vocab_src, vocab_trg)``; the encoder half runs the same kernels at prefill shapes."""
+
+    def __init__(self, hp, vocab_src, vocab_trg, device='cuda'):
+        super().__init__(device)
+        from .encoder import TransformerEncoder
+        self.encoder = TransformerEncoder(hp, vocab_src, device)
+        self.decoder = TransformerDecoder(hp, vocab_trg, device)
+
+    def state_dict(self):
+        sd = OrderedDict(('encoder.' + k, v) for k, v in self.encoder.state_dict().items())
+        sd.update(('decoder.' + k, v) for k, v in self.decoder.state_dict().items())
+        return sd
+
+    def load_state_dict(self, sd, strict=True):
+        self.encoder.load_state_dict({k[8:]: v for k, v in sd.items() if k.startswith('encoder.')}, strict)
+        self.decoder.load_state_dict({k[8:]: v for k, v in sd.items() if k.startswith('decoder.')}, strict)
+        return self
+
+    def parameters(self):
+        return self.encoder.parameters() + self.decoder.parameters()
+
+    def to(self, device):
+        self.encoder.to(device)
+        self.decoder.to(device)
+        return self
+
+    def __call__(self, src, trg):
+        encs, enc_mask = self.encoder(src)
+        return self.decoder(encs, trg[:, :-1], enc_mask)
