@@ -132,7 +132,7 @@ def random_case(T, V, B, S, max_len, eos_bias, seed, hp=None):
 def test_random_batch_bit_exact_vs_oracle(T, beam, alpha):
     """64 sentences, V=2048, ragged sources: tokens and scores identical to the canonical oracle; the
     batch shrinks as sentences finish, so compaction and beam reordering are exercised."""
-    tmodel, model, vocab, encs, mask = random_case(T, 2048, 64, 20, 24, 2.0 if beam == 1 else 0.5, 7)
+    tmodel, model, vocab, encs, mask = random_case(T, 2048, 64, 20, 24, 2.0 if beam == 1 else 3.0, 7)
     st = T.InferenceState({'model': model.decoder, 'inputs': torch.from_numpy(encs).cuda(), 'enc_mask': torch.from_numpy(mask).cuda(),
                            'vocab': vocab, 'max_len': 24, 'beam_size': beam, 'length_penalty': alpha})
     out = seqs_of(st.inference(keep_logits=3))
@@ -177,12 +177,12 @@ def test_foreign_model_callable(T):
     GPU, called once per step on the whole prefix like /root/reference/src/inference.py:132."""
     fx = load_fixture('tfm_v64')
     tmodel, model, vocab = native_models(T, fx['config'])
-    tdec = tmodel.decoder.cuda()
-    st = state_for(T, fx, model, vocab, model=tdec)
+    import types
+    st = state_for(T, fx, types.SimpleNamespace(decoder=tmodel.decoder.cuda()), vocab)
     assert seqs_of(st.inference()) == fx['seqs']
     fx = load_fixture('rnnlm_stateful')
     tmodel, model, vocab = native_models(T, fx['config'])
-    st = state_for(T, fx, model, vocab, model=tmodel.cuda())
+    st = state_for(T, fx, tmodel.cuda(), vocab)
     assert seqs_of(st.inference()) == fx['seqs']
 
 

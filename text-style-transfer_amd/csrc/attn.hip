@@ -30,7 +30,6 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
     const int pos = n - 1;
 
     const float* qp;
-    const float* kbase;  // + p-dependent offset
     int64_t ent = 0;
     if (SELF) {
         for (int p = lane; p < n; p += 64) slot[w][p] = (p < pos) ? anc[r * anc_ld + p] : (int)r;
@@ -39,7 +38,6 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
         ent = sent[r];
         qp = qbuf + r * d + h * dh;
     }
-    (void)kbase;
     const int j = lane & 15, g = lane >> 4;
     float4 qv[NCH];
 #pragma unroll
@@ -140,7 +138,7 @@ int launch_attn(const float* base, int64_t slab_stride, const int32_t* anc, int6
                 const uint8_t* mask, const int32_t* sent, int64_t n, float* out, int64_t R, int64_t d, int64_t heads,
                 hipStream_t stream, const char* name) {
     const int64_t dh = d / heads;
-    const float scale = 1.0f / sqrtf((float)dh);
+    const float scale = (float)(1.0 / sqrt((double)dh));  // rounded once, from the double-precision value
     const unsigned grid = (unsigned)((R * heads + 3) / 4);
     const int nch = (int)((dh + 63) / 64);
     const int vec = (dh % 256 == 0) ? 4 : (dh % 128 == 0) ? 2 : 1;
