@@ -6,6 +6,11 @@ if it is missing, importing this module raises, and every wrapper raises on a no
 import ctypes
 import os
 
+# torch must be loaded first: the library's dependency on libamdhip64.so.7 then binds to the HIP runtime
+# that torch already loaded, so both share one runtime (device pointers, streams).  Loaded the other way
+# round the process ends up with two HIP runtimes and the second one finds no device.
+import torch  # noqa: F401
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libtst_hip.so')
 

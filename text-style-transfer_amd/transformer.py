@@ -111,6 +111,7 @@ class TransformerDecoder(HipModule):
         self.hp, self.vocab = hp, vocab
         d, V, ff = hp.d_model, len(vocab), hp.d_ff
         self.d, self.V, self.heads, self.n_layers = d, V, hp.n_heads, hp.n_layers
+        self.event_log = None  # set to a list to collect (start, end, flops) of every vocabulary projection
         if d % hp.n_heads or (d // hp.n_heads) % 4 or d % 4:
             raise ValueError('d_model / n_heads must be a multiple of 4')
         s = 1.0 / math.sqrt(d)
@@ -252,7 +253,15 @@ class TransformerSession:
             K.gemm(h, L['w1'], L['b1'], ff, n, act=1)
             K.gemm(ff, L['w2'], L['b2'], x, n, res=x)
         K.layernorm(x, W['ln'][0], W['ln'][1], h, n)
-        K.gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
+        log = dec.event_log
+        if log is None:
+            K.gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
+        else:  # measurement aid: HIP events on the launch stream around the vocabulary projection
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            K.gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
+            e1.record()
+            log.append((e0, e1, 2.0 * n * d * self.V))
         return self.logits
 
 
