@@ -109,7 +109,10 @@ int tst_greedy_select(const int32_t* argmax_tok, int64_t n_rows, int32_t eos, in
                       float* sel_score, int32_t* sel_fin, int32_t* sel_nemit, const tst_rows* cur, void* stream);
 
 /* Retire finished sentences and compact the batch: /root/reference/src/inference.py:94-120 and :65-69.
- * A sentence ends when all its k new beams are finished or when last_step != 0; its best beam
+ * A sentence ends when all its k new beams are finished, when last_step != 0, or - if top_ends != 0 - when
+ * its top beam (slot 0, the highest score) is finished.  With a length penalty of 0 a finished top beam
+ * can never be overtaken (scores only decrease, ties go to the lower slot), so top_ends = 1 then gives
+ * the same outputs as waiting for all beams, in fewer steps.  The sentence's best beam
  * (score / lp[nemit], ties: lower beam; lp = length-penalty table of T + 2 floats) is written to
  * out_tok[sentence][0..T], out_len (BOS included, EOS stripped) and out_score.  Surviving sentences keep
  * their order; their rows are gathered from `cur` through sel_parent into `nxt`, the new token is
@@ -118,9 +121,9 @@ int tst_greedy_select(const int32_t* argmax_tok, int64_t n_rows, int32_t eos, in
  * n_alive (device, 1 int32) receives the number of surviving sentences.  Three launches on `stream`. */
 int tst_retire_compact(const tst_rows* cur, const tst_rows* nxt, const int32_t* sel_parent, const int32_t* sel_tok,
                        const float* sel_score, const int32_t* sel_fin, const int32_t* sel_nemit, const float* lp,
-                       int64_t n_sent, int64_t k, int64_t step, int64_t T, int32_t eos, int last_step, int32_t* out_tok,
-                       int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent,
-                       int32_t* n_alive, void* stream);
+                       int64_t n_sent, int64_t k, int64_t step, int64_t T, int32_t eos, int last_step, int top_ends,
+                       int32_t* out_tok, int32_t* out_len, float* out_score, int32_t* scratch_alive_pos,
+                       int32_t* row_parent, int32_t* n_alive, void* stream);
 
 #ifdef __cplusplus
 }

@@ -138,17 +138,21 @@ def test_random_batch_bit_exact_vs_oracle(T, beam, alpha):
     out = seqs_of(st.inference(keep_logits=3))
     sess = C.CanonTransformerDecoder(tmodel.decoder, 2).session(encs, mask, beam, 24)
     if beam == 1:
-        want, logs, _ = C.greedy_decode(sess, 64, 24, 2, 3, 3)
+        want, logs, alive = C.greedy_decode(sess, 64, 24, 2, 3, 3)
     else:
-        want, scores, logs, _ = C.beam_decode(sess, 64, beam, 24, 2, 3, alpha, 3)
+        want, scores, logs, alive = C.beam_decode(sess, 64, beam, 24, 2, 3, alpha, 3)
         assert np.array_equal(st.scores.cpu().numpy(), scores)
     assert out == want
     lens = [len(s) for s in out]
     assert min(lens) < 25 and len(set(lens)) > 3                         # ragged termination really happened
     for i in range(3):
-        lg, _, fin = st.loop.kept[i]
-        live = fin.cpu().numpy() == 0
-        assert np.array_equal(lg.cpu().numpy()[live], logs[i][live])
+        # rows of the sentences still alive on the GPU (it may retire a sentence earlier than the oracle:
+        # with no length penalty a finished top beam is final), beam by beam
+        lg, sent, fin = (x.cpu().numpy() for x in st.loop.kept[i])
+        first_row = {int(s): a * beam for a, s in enumerate(alive[i])}
+        orc_rows = np.array([first_row[int(s)] for s in sent[::beam]])[:, None] + np.arange(beam)[None]
+        live = fin == 0
+        assert np.array_equal(lg[live], logs[i][orc_rows.reshape(-1)][live])
 
 
 def test_beam_one_equals_greedy_and_batch_independence(T):

@@ -16,11 +16,11 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 16, LDT = 132, GROUP_M = 16;
 
+template <bool FULL_K, bool HAS_RES, bool RELU>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ W, int64_t ldw,
                                                        const float* __restrict__ bias, const float* res, int64_t ldr,
-                                                       float* C, int64_t ldc, int M, int N, int K, int act, int tiles_m,
-                                                       int tiles_n) {
+                                                       float* C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDT];
 
@@ -48,15 +48,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int bk0 = t >> 5, bk1 = (t + 256) >> 5, bnq = (t & 31) * 4;
     const float* a_row0 = A + (int64_t)min(m0 + ar0, M - 1) * lda;
     const float* a_row1 = A + (int64_t)min(m0 + ar1, M - 1) * lda;
-    const bool b_in = n0 + bnq < ldw;
 
+    // Loads are unconditional from clamped (always valid) addresses and out-of-range data is zeroed
+    // afterwards: a conditional load would be compiled to a select between addresses and lose the
+    // 16-byte global_load.
+    const int bcol_g = min(n0 + bnq, (int)ldw - 4);
 #define TST_LOAD_TILE(k0)                                                                                       \
     do {                                                                                                        \
         const int gk_ = (k0) + akq;                                                                             \
-        ra0 = gk_ < K ? *reinterpret_cast<const float4*>(a_row0 + gk_) : zero4;                                 \
-        ra1 = gk_ < K ? *reinterpret_cast<const float4*>(a_row1 + gk_) : zero4;                                 \
-        rb0 = (b_in && (k0) + bk0 < K) ? *reinterpret_cast<const float4*>(W + (int64_t)((k0) + bk0) * ldw + n0 + bnq) : zero4; \
-        rb1 = (b_in && (k0) + bk1 < K) ? *reinterpret_cast<const float4*>(W + (int64_t)((k0) + bk1) * ldw + n0 + bnq) : zero4; \
+        const int gkc_ = min(gk_, K - 4);                                                                       \
+        ra0 = *reinterpret_cast<const float4*>(a_row0 + gkc_);                                                  \
+        ra1 = *reinterpret_cast<const float4*>(a_row1 + gkc_);                                                  \
+        rb0 = *reinterpret_cast<const float4*>(W + (int64_t)min((k0) + bk0, K - 1) * ldw + bcol_g);            \
+        rb1 = *reinterpret_cast<const float4*>(W + (int64_t)min((k0) + bk1, K - 1) * ldw + bcol_g);            \
+        if (!FULL_K) {                                                                                          \
+            if (gk_ >= K) { ra0 = zero4; ra1 = zero4; }                                                         \
+            if ((k0) + bk0 >= K) rb0 = zero4;                                                                   \
+            if ((k0) + bk1 >= K) rb1 = zero4;                                                                   \
+        }                                                                                                       \
     } while (0)
 #define TST_STORE_TILE(buf)                                                                                     \
     do {                                                                                                        \
@@ -101,20 +110,29 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         __syncthreads();
     }
 
+    // epilogue: lane owns column col of 16 rows per 32 x 32 tile (rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+            const int row0 = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+            const bool col_ok = col < N;
+            float rv[16];
+            if (HAS_RES) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + (r & 3) + 8 * (r >> 2);
+                    rv[r] = (col_ok && row < M) ? res[(int64_t)row * ldr + col] : 0.0f;
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < M && col < N) {
-                    float v = acc[i][j][r];
-                    if (act == 1) v = v > 0.0f ? v : 0.0f;
-                    if (res != nullptr) v = v + res[(int64_t)row * ldr + col];
-                    C[(int64_t)row * ldc + col] = v;
-                }
+                const int row = row0 + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][j][r];
+                if (RELU) v = v > 0.0f ? v : 0.0f;
+                if (HAS_RES) v = v + rv[r];
+                if (col_ok && row < M) C[(int64_t)row * ldc + col] = v;
             }
         }
 }
@@ -125,7 +143,7 @@ extern "C" int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, i
                                  const float* res, int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                                  int act, void* stream) {
     TST_REQUIRE(A && Wt && C, TST_ERR_ARG, "tst_gemm_mfma_f32: null pointer");
-    TST_REQUIRE(M >= 0 && N > 0 && K > 0, TST_ERR_ARG, "tst_gemm_mfma_f32: bad sizes M=%lld N=%lld K=%lld", (long long)M,
+    TST_REQUIRE(M >= 0 && N > 0 && K >= 4 && (act == 0 || act == 1), TST_ERR_ARG, "tst_gemm_mfma_f32: bad sizes M=%lld N=%lld K=%lld", (long long)M,
                 (long long)N, (long long)K);
     TST_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= K && ldw >= N && ldc >= N, TST_ERR_ARG,
                 "tst_gemm_mfma_f32: K, lda, ldw must be multiples of 4 and lda >= K, ldw >= N, ldc >= N");
@@ -135,7 +153,23 @@ extern "C" int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, i
     if (M == 0) return TST_OK;
     const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     TST_REQUIRE(tiles_m * tiles_n < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_f32: grid too large");
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, (hipStream_t)stream, A, lda, Wt,
-                       ldw, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, act, (int)tiles_m, (int)tiles_n);
+    const dim3 grid((unsigned)(tiles_m * tiles_n));
+    hipStream_t st = (hipStream_t)stream;
+    const bool full_k = K % BK == 0;
+#define TST_GEMM_LAUNCH(FK, HR, RL)                                                                               \
+    hipLaunchKernelGGL((gemm_f32_kernel<FK, HR, RL>), grid, dim3(256), 0, st, A, lda, Wt, ldw, bias, res, ldr, C, ldc, \
+                       (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n)
+    const int variant = (full_k ? 4 : 0) | (res != nullptr ? 2 : 0) | (act == 1 ? 1 : 0);
+    switch (variant) {
+        case 0: TST_GEMM_LAUNCH(false, false, false); break;
+        case 1: TST_GEMM_LAUNCH(false, false, true); break;
+        case 2: TST_GEMM_LAUNCH(false, true, false); break;
+        case 3: TST_GEMM_LAUNCH(false, true, true); break;
+        case 4: TST_GEMM_LAUNCH(true, false, false); break;
+        case 5: TST_GEMM_LAUNCH(true, false, true); break;
+        case 6: TST_GEMM_LAUNCH(true, true, false); break;
+        default: TST_GEMM_LAUNCH(true, true, true); break;
+    }
+#undef TST_GEMM_LAUNCH
     return tst_after_launch("tst_gemm_mfma_f32");
 }

@@ -261,14 +261,15 @@ __global__ __launch_bounds__(256) void finish_kernel(tst_rows cur, const int32_t
                                                      const int32_t* __restrict__ tok, const float* __restrict__ score,
                                                      const int32_t* __restrict__ fin, const int32_t* __restrict__ nemit,
                                                      const float* __restrict__ lp, int64_t n_sent, int k, int T,
-                                                     int last_step, int32_t* out_tok, int32_t* out_len, float* out_score,
-                                                     int32_t* alive) {
+                                                     int last_step, int top_ends, int32_t* out_tok, int32_t* out_len,
+                                                     float* out_score, int32_t* alive) {
     const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (a >= n_sent) return;
     const int64_t base = a * k;
     bool all_fin = true;
     for (int j = 0; j < k; ++j) all_fin = all_fin && fin[base + j] != 0;
-    const bool done = all_fin || last_step != 0;
+    // top_ends: the best beam (slot 0, the highest score) has ended and nothing can overtake it
+    const bool done = all_fin || last_step != 0 || (top_ends != 0 && fin[base] != 0);
     alive[a] = done ? 0 : 1;
     if (!done) return;
     int best = 0;
@@ -423,9 +424,9 @@ extern "C" int tst_beam_merge(const tst_rows* cur, const float* top_val, const i
 extern "C" int tst_retire_compact(const tst_rows* cur, const tst_rows* nxt, const int32_t* sel_parent,
                                   const int32_t* sel_tok, const float* sel_score, const int32_t* sel_fin,
                                   const int32_t* sel_nemit, const float* lp, int64_t n_sent, int64_t k, int64_t step,
-                                  int64_t T, int32_t eos, int last_step, int32_t* out_tok, int32_t* out_len,
-                                  float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent, int32_t* n_alive,
-                                  void* stream) {
+                                  int64_t T, int32_t eos, int last_step, int top_ends, int32_t* out_tok,
+                                  int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent,
+                                  int32_t* n_alive, void* stream) {
     (void)eos;
     TST_REQUIRE(rows_ok(cur, false) && rows_ok(nxt, cur && cur->anc) && sel_parent && sel_tok && sel_score && sel_fin &&
                     sel_nemit && lp && out_tok && out_len && out_score && scratch_alive_pos && row_parent && n_alive,
@@ -437,8 +438,8 @@ extern "C" int tst_retire_compact(const tst_rows* cur, const tst_rows* nxt, cons
     int32_t* pos = scratch_alive_pos + n_sent;
     if (n_sent > 0) {
         hipLaunchKernelGGL(finish_kernel, dim3(blocks_for(n_sent, 256)), dim3(256), 0, st, *cur, sel_parent, sel_tok,
-                           sel_score, sel_fin, sel_nemit, lp, n_sent, (int)k, (int)T, last_step, out_tok, out_len, out_score,
-                           alive);
+                           sel_score, sel_fin, sel_nemit, lp, n_sent, (int)k, (int)T, last_step, top_ends, out_tok, out_len,
+                           out_score, alive);
     }
     hipLaunchKernelGGL(scan_alive_kernel, dim3(1), dim3(1024), 0, st, alive, pos, n_sent, n_alive);
     if (n_sent > 0) {

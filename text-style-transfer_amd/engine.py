@@ -30,6 +30,8 @@ class DecodeLoop:
             raise ValueError('beam_size larger than the vocabulary')
         self.s, self.B, self.k, self.T = session, n_sent, beam, max_len
         self.bos, self.eos = int(bos), int(eos)
+        # with no length penalty a finished top beam is final (see tst_retire_compact): end the sentence there
+        self.top_ends = beam > 1 and float(alpha) == 0.0
         dev = device or torch.device('cuda', torch.cuda.current_device())
         self.dev = dev
         R = n_sent * beam
@@ -76,8 +78,8 @@ class DecodeLoop:
             else:
                 K.logsoftmax_topk(logits, R, s.V, k, self.top_val, self.top_idx, self.lse)
                 K.beam_merge(self.cur, self.top_val, self.top_idx, self.lse, n_sent, k, t, self.eos, self.sel)
-            K.retire_compact(self.cur, self.nxt, self.sel, self.lp, n_sent, k, t, T, self.eos, t == T - 1, self.out_tok,
-                             self.out_len, self.out_score, self.scratch, self.row_parent, self.n_alive)
+            K.retire_compact(self.cur, self.nxt, self.sel, self.lp, n_sent, k, t, T, self.eos, t == T - 1, self.top_ends,
+                             self.out_tok, self.out_len, self.out_score, self.scratch, self.row_parent, self.n_alive)
             self.cur, self.nxt = self.nxt, self.cur
             self.steps_done += 1
             self.rows_stepped += R

@@ -140,8 +140,8 @@ def beam_merge(cur, top_val, top_idx, lse, n_sent, k, step, eos, sel):
     call('tst_beam_merge', st, _p(top_val), _p(top_idx), _p(lse), n_sent, k, step, eos, *sel.ptrs(), _stream())
 
 
-def retire_compact(cur, nxt, sel, lp, n_sent, k, step, T, eos, last_step, out_tok, out_len, out_score, scratch, row_parent,
-                   n_alive):
+def retire_compact(cur, nxt, sel, lp, n_sent, k, step, T, eos, last_step, top_ends, out_tok, out_len, out_score, scratch,
+                   row_parent, n_alive):
     a, b = cur.struct(), nxt.struct()
-    call('tst_retire_compact', a, b, *sel.ptrs(), _p(lp), n_sent, k, step, T, eos, int(last_step), _p(out_tok), _p(out_len),
+    call('tst_retire_compact', a, b, *sel.ptrs(), _p(lp), n_sent, k, step, T, eos, int(last_step), int(top_ends), _p(out_tok), _p(out_len),
          _p(out_score), _p(scratch), _p(row_parent), _p(n_alive), _stream())
