@@ -3,7 +3,8 @@
 // v_mfma_f32_32x32x2_f32 accumulates exactly like a k-ordered fmaf chain (one rounding per term),
 // so every output element is  acc = bias[n]; for k ascending: acc = fma(A[m][k], Wt[k][n], acc)
 // whatever the tiling.  Tile: 128 x 128 x 16 per 256-thread workgroup; 4 waves as 2 (M) x 2 (N), each
-// wave owns 64 x 64 = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator registers).  A and Wt tiles are
+// wave owns 64 x 64 = 2 x 2 MFMA tiles of 32 x 32 (64 accumulator registers); small problems use
+// 64 x 64 x 16 tiles (one MFMA tile per wave) so that every CU gets work.  A and Wt tiles are
 // staged through registers into k-major LDS images ([k][m] and [k][n]) so that the one-float-per-lane
 // MFMA operands are conflict-free ds_read_b32; global loads of tile t+1 are in flight while tile t is
 // multiplied (two LDS buffers, one barrier per tile).  Workgroups are renumbered so that each XCD
@@ -14,13 +15,17 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 16, LDT = 132, GROUP_M = 16;
+constexpr int BK = 16, GROUP_M = 16;
 
-template <bool FULL_K, bool HAS_RES, bool RELU>
+// WT = MFMA tiles (32 x 32) per wave and dimension: the workgroup tile is (64 * WT) x (64 * WT).
+// WT = 2 (128 x 128) for large problems; WT = 1 (64 x 64) when the 128-tiling would leave CUs without work.
+template <int WT, bool FULL_K, bool HAS_RES, bool RELU>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ W, int64_t ldw,
                                                        const float* __restrict__ bias, const float* res, int64_t ldr,
                                                        float* C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr int BM = 64 * WT, BN = 64 * WT, LDT = BM + 4;
+    constexpr int NLD = WT;  // float4 loads per thread and operand: BM * BK / 4 / 256
     __shared__ __attribute__((aligned(16))) float As[2][BK][LDT];
     __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDT];
 
@@ -41,49 +46,56 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     const int lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // staging registers for the next tile: 2 float4 of A (rows ar0/ar1, k offset akq) and 2 of Wt
-    float4 ra0, ra1, rb0, rb1;
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int ar0 = t >> 2, ar1 = (t + 256) >> 2, akq = (t & 3) * 4;
-    const int bk0 = t >> 5, bk1 = (t + 256) >> 5, bnq = (t & 31) * 4;
-    const float* a_row0 = A + (int64_t)min(m0 + ar0, M - 1) * lda;
-    const float* a_row1 = A + (int64_t)min(m0 + ar1, M - 1) * lda;
-
+    // Staging registers for the next tile.  A: float4 along k of row ar[j]; Wt: float4 along n of k-row bk[j].
     // Loads are unconditional from clamped (always valid) addresses and out-of-range data is zeroed
     // afterwards: a conditional load would be compiled to a select between addresses and lose the
     // 16-byte global_load.
+    float4 ra0, ra1, rb0, rb1;  // named registers (arrays here end up in scratch memory); *1 unused when WT == 1
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int akq = (t & 3) * 4;
+    const int bnq = (t % (BN / 4)) * 4;
+    const int ar0 = t >> 2, ar1 = (t + 256) >> 2;
+    const int bk0 = t / (BN / 4), bk1 = (t + 256) / (BN / 4);
+    const float* a_row0 = A + (int64_t)min(m0 + ar0, M - 1) * lda;
+    const float* a_row1 = A + (int64_t)min(m0 + ar1, M - 1) * lda;
     const int bcol_g = min(n0 + bnq, (int)ldw - 4);
-#define TST_LOAD_TILE(k0)                                                                                       \
-    do {                                                                                                        \
-        const int gk_ = (k0) + akq;                                                                             \
-        const int gkc_ = min(gk_, K - 4);                                                                       \
-        ra0 = *reinterpret_cast<const float4*>(a_row0 + gkc_);                                                  \
-        ra1 = *reinterpret_cast<const float4*>(a_row1 + gkc_);                                                  \
-        rb0 = *reinterpret_cast<const float4*>(W + (int64_t)min((k0) + bk0, K - 1) * ldw + bcol_g);            \
-        rb1 = *reinterpret_cast<const float4*>(W + (int64_t)min((k0) + bk1, K - 1) * ldw + bcol_g);            \
-        if (!FULL_K) {                                                                                          \
-            if (gk_ >= K) { ra0 = zero4; ra1 = zero4; }                                                         \
-            if ((k0) + bk0 >= K) rb0 = zero4;                                                                   \
-            if ((k0) + bk1 >= K) rb1 = zero4;                                                                   \
-        }                                                                                                       \
+    ra1 = zero4; rb1 = zero4;
+
+#define TST_LOAD_TILE(k0)                                                                                     \
+    do {                                                                                                      \
+        const int gk_ = (k0) + akq;                                                                           \
+        const int gkc_ = min(gk_, K - 4);                                                                     \
+        ra0 = *reinterpret_cast<const float4*>(a_row0 + gkc_);                                                \
+        rb0 = *reinterpret_cast<const float4*>(W + (int64_t)min((k0) + bk0, K - 1) * ldw + bcol_g);           \
+        if (NLD == 2) {                                                                                       \
+            ra1 = *reinterpret_cast<const float4*>(a_row1 + gkc_);                                            \
+            rb1 = *reinterpret_cast<const float4*>(W + (int64_t)min((k0) + bk1, K - 1) * ldw + bcol_g);       \
+        }                                                                                                     \
+        if (!FULL_K) {                                                                                        \
+            if (gk_ >= K) { ra0 = zero4; ra1 = zero4; }                                                       \
+            if ((k0) + bk0 >= K) rb0 = zero4;                                                                 \
+            if ((k0) + bk1 >= K) rb1 = zero4;                                                                 \
+        }                                                                                                     \
     } while (0)
-#define TST_STORE_TILE(buf)                                                                                     \
-    do {                                                                                                        \
-        As[buf][akq + 0][ar0] = ra0.x; As[buf][akq + 1][ar0] = ra0.y;                                           \
-        As[buf][akq + 2][ar0] = ra0.z; As[buf][akq + 3][ar0] = ra0.w;                                           \
-        As[buf][akq + 0][ar1] = ra1.x; As[buf][akq + 1][ar1] = ra1.y;                                           \
-        As[buf][akq + 2][ar1] = ra1.z; As[buf][akq + 3][ar1] = ra1.w;                                           \
-        *reinterpret_cast<float4*>(&Bs[buf][bk0][bnq]) = rb0;                                                   \
-        *reinterpret_cast<float4*>(&Bs[buf][bk1][bnq]) = rb1;                                                   \
+#define TST_STORE_TILE(buf)                                                                                   \
+    do {                                                                                                      \
+        As[buf][akq + 0][ar0] = ra0.x; As[buf][akq + 1][ar0] = ra0.y;                                         \
+        As[buf][akq + 2][ar0] = ra0.z; As[buf][akq + 3][ar0] = ra0.w;                                         \
+        *reinterpret_cast<float4*>(&Bs[buf][bk0][bnq]) = rb0;                                                 \
+        if (NLD == 2) {                                                                                       \
+            As[buf][akq + 0][ar1] = ra1.x; As[buf][akq + 1][ar1] = ra1.y;                                     \
+            As[buf][akq + 2][ar1] = ra1.z; As[buf][akq + 3][ar1] = ra1.w;                                     \
+            *reinterpret_cast<float4*>(&Bs[buf][bk1][bnq]) = rb1;                                             \
+        }                                                                                                     \
     } while (0)
 
-    f32x16 acc[2][2];
+    f32x16 acc[WT][WT];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int col = n0 + wn * 64 + j * 32 + (lane & 31);
+    for (int j = 0; j < WT; ++j) {
+        const int col = n0 + wn * 32 * WT + j * 32 + (lane & 31);
         const float b = (bias != nullptr && col < N) ? bias[col] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WT; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = b;
     }
@@ -92,19 +104,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     TST_LOAD_TILE(0);
     TST_STORE_TILE(0);
     __syncthreads();
-    const int arow = wm * 64 + (lane & 31), bcol = wn * 64 + (lane & 31), khalf = lane >> 5;
+    const int arow = wm * 32 * WT + (lane & 31), bcol = wn * 32 * WT + (lane & 31), khalf = lane >> 5;
     for (int kt = 0; kt < nkt; ++kt) {
         const int buf = kt & 1;
         if (kt + 1 < nkt) TST_LOAD_TILE((kt + 1) * BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const int kr = kk + khalf;
-            const float a0 = As[buf][kr][arow], a1 = As[buf][kr][arow + 32];
-            const float b0 = Bs[buf][kr][bcol], b1 = Bs[buf][kr][bcol + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+            float av[WT], bv[WT];
+#pragma unroll
+            for (int i = 0; i < WT; ++i) {
+                av[i] = As[buf][kr][arow + 32 * i];
+                bv[i] = Bs[buf][kr][bcol + 32 * i];
+            }
+#pragma unroll
+            for (int i = 0; i < WT; ++i)
+#pragma unroll
+                for (int j = 0; j < WT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
         }
         if (kt + 1 < nkt) TST_STORE_TILE(buf ^ 1);
         __syncthreads();
@@ -112,11 +129,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 
     // epilogue: lane owns column col of 16 rows per 32 x 32 tile (rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WT; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + (lane & 31);
-            const int row0 = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+        for (int j = 0; j < WT; ++j) {
+            const int col = n0 + wn * 32 * WT + j * 32 + (lane & 31);
+            const int row0 = m0 + wm * 32 * WT + i * 32 + 4 * (lane >> 5);
             const bool col_ok = col < N;
             float rv[16];
             if (HAS_RES) {
@@ -137,6 +154,32 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         }
 }
 
+#undef TST_LOAD_TILE
+#undef TST_STORE_TILE
+
+template <int WT>
+void launch_gemm(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res, int64_t ldr,
+                 float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st) {
+    constexpr int BT = 64 * WT;
+    const int64_t tiles_m = (M + BT - 1) / BT, tiles_n = (N + BT - 1) / BT;
+    const dim3 grid((unsigned)(tiles_m * tiles_n));
+#define TST_GEMM_LAUNCH(FK, HR, RL)                                                                                    \
+    hipLaunchKernelGGL((gemm_f32_kernel<WT, FK, HR, RL>), grid, dim3(256), 0, st, A, lda, Wt, ldw, bias, res, ldr, C, ldc, \
+                       (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n)
+    const int variant = (K % BK == 0 ? 4 : 0) | (res != nullptr ? 2 : 0) | (act == 1 ? 1 : 0);
+    switch (variant) {
+        case 0: TST_GEMM_LAUNCH(false, false, false); break;
+        case 1: TST_GEMM_LAUNCH(false, false, true); break;
+        case 2: TST_GEMM_LAUNCH(false, true, false); break;
+        case 3: TST_GEMM_LAUNCH(false, true, true); break;
+        case 4: TST_GEMM_LAUNCH(true, false, false); break;
+        case 5: TST_GEMM_LAUNCH(true, false, true); break;
+        case 6: TST_GEMM_LAUNCH(true, true, false); break;
+        default: TST_GEMM_LAUNCH(true, true, true); break;
+    }
+#undef TST_GEMM_LAUNCH
+}
+
 }  // namespace
 
 extern "C" int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias,
@@ -151,25 +194,12 @@ extern "C" int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, i
     TST_REQUIRE(res == nullptr || ldr >= N, TST_ERR_ARG, "tst_gemm_mfma_f32: ldr < N");
     TST_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_f32: size");
     if (M == 0) return TST_OK;
-    const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-    TST_REQUIRE(tiles_m * tiles_n < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_f32: grid too large");
-    const dim3 grid((unsigned)(tiles_m * tiles_n));
-    hipStream_t st = (hipStream_t)stream;
-    const bool full_k = K % BK == 0;
-#define TST_GEMM_LAUNCH(FK, HR, RL)                                                                               \
-    hipLaunchKernelGGL((gemm_f32_kernel<FK, HR, RL>), grid, dim3(256), 0, st, A, lda, Wt, ldw, bias, res, ldr, C, ldc, \
-                       (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n)
-    const int variant = (full_k ? 4 : 0) | (res != nullptr ? 2 : 0) | (act == 1 ? 1 : 0);
-    switch (variant) {
-        case 0: TST_GEMM_LAUNCH(false, false, false); break;
-        case 1: TST_GEMM_LAUNCH(false, false, true); break;
-        case 2: TST_GEMM_LAUNCH(false, true, false); break;
-        case 3: TST_GEMM_LAUNCH(false, true, true); break;
-        case 4: TST_GEMM_LAUNCH(true, false, false); break;
-        case 5: TST_GEMM_LAUNCH(true, false, true); break;
-        case 6: TST_GEMM_LAUNCH(true, true, false); break;
-        default: TST_GEMM_LAUNCH(true, true, true); break;
-    }
-#undef TST_GEMM_LAUNCH
+    TST_REQUIRE(((M + 63) / 64) * ((N + 63) / 64) < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_f32: grid too large");
+    // 128 x 128 tiles unless they would give fewer than two workgroups per CU (256 CUs): then 64 x 64
+    const int64_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128);
+    if (big_tiles >= 512)
+        launch_gemm<2>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
+    else
+        launch_gemm<1>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
     return tst_after_launch("tst_gemm_mfma_f32");
 }
