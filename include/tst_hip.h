@@ -75,6 +75,13 @@ int tst_gather_rows_f32(const float* src, const int32_t* idx, float* dst, int64_
  * /root/reference/src/inference.py:145. */
 int tst_argmax_rows_f32(const float* logits, int64_t ld, int64_t R, int64_t V, int32_t* tok, void* stream);
 
+/* tok[r] ~ Categorical(logits = logits[r] / temperature): Categorical(...).sample() at
+ * /root/reference/src/inference.py:147, drawn by the Gumbel-max trick, argmax_v (x_v / temperature - log(-log u_v)),
+ * with u_v in (0,1) from a counter-based hash of (seed, step, sent[r], v), so a sentence's draws do not depend on
+ * which other rows are in the batch. */
+int tst_sample_rows_f32(const float* logits, int64_t ld, int64_t R, int64_t V, float temperature, uint32_t seed,
+                        uint32_t step, const int32_t* sent, int32_t* tok, void* stream);
+
 /* Per row: lse[r] = log sum exp(logits[r]) and the k largest logits (value descending, index ascending),
  * 1 <= k <= 8, k <= V.  Feeds tst_beam_merge (the reference has no beam search; build-defined). */
 int tst_logsoftmax_topk_f32(const float* logits, int64_t ld, int64_t R, int64_t V, int64_t k, float* top_val,

@@ -259,3 +259,34 @@ void orc_logsoftmax_topk(const float* x, int64_t ld, int64_t R, int64_t V, int k
         }
     }
 }
+
+/* ------------------------------------------------------------------ sampling (Gumbel-max) */
+/* Restates Categorical(logits = x / temperature).sample() of /root/reference/src/inference.py:147 as
+ * argmax_v (x_v / temperature + g_v), g_v = -log(-log(u_v)), with u_v in (0,1) from a counter-based integer
+ * hash of (seed, step, sentence, v): the draw for a sentence does not depend on the other rows of the batch.
+ * First maximal index wins ties. */
+static inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+float orc_gumbel(uint32_t seed, uint32_t step, uint32_t sent, uint32_t v) {
+    uint32_t h = mix32(v ^ mix32(sent * 0x9E3779B9u + mix32(step * 0x85EBCA6Bu + seed)));
+    float u = (float)(h >> 9) * 1.1920928955078125e-07f + 5.9604644775390625e-08f; /* ((h >> 9) + 0.5) / 2^23: exact in fp32, inside (0, 1) */
+    return -orc_log(-orc_log(u));
+}
+
+void orc_sample_rows(const float* x, int64_t ld, int64_t R, int64_t V, float temperature, uint32_t seed, uint32_t step,
+                     const int32_t* sent, int32_t* out) {
+#pragma omp parallel for
+    for (int64_t r = 0; r < R; ++r) {
+        const float* xr = x + r * ld;
+        int64_t best = 0;
+        float bv = -INFINITY;
+        for (int64_t v = 0; v < V; ++v) {
+            float key = xr[v] / temperature + orc_gumbel(seed, step, (uint32_t)sent[r], (uint32_t)v);
+            if (key > bv) { bv = key; best = v; }
+        }
+        out[r] = (int32_t)best;
+    }
+}

@@ -149,6 +149,15 @@ def logsoftmax_topk(x, k):
     return val, idx, lse
 
 
+def sample_rows(x, temperature, seed, step, sent):
+    x, px = _f(x)
+    sent, ps = _i(sent)
+    out = np.empty(x.shape[0], dtype=np.int32)
+    lib().orc_sample_rows(px, _i64(x.shape[1]), _i64(x.shape[0]), _i64(x.shape[1]), ctypes.c_float(temperature),
+                          ctypes.c_uint32(seed), ctypes.c_uint32(step), ps, out.ctypes.data_as(_i32p))
+    return out
+
+
 # --------------------------------------------------------------------------------------------
 # models (weights come from a torch state_dict; Linear weights are stored transposed, [in, out])
 # --------------------------------------------------------------------------------------------
@@ -315,10 +324,11 @@ class _GRUSession:
 # --------------------------------------------------------------------------------------------
 # decode loops
 # --------------------------------------------------------------------------------------------
-def greedy_decode(sess, B, max_len, bos, eos, keep_logits=0):
+def greedy_decode(sess, B, max_len, bos, eos, keep_logits=0, sample=None):
     """Greedy loop with the data flow of /root/reference/src/inference.py:154-167: rows whose new token
     is EOS are stored without it and leave the batch; rows alive after ``max_len`` steps are stored as
-    they are (1 + max_len tokens).  Returns (sequences, [logits per kept step], [rows per kept step])."""
+    they are (1 + max_len tokens).  ``sample=(temperature, seed)`` replaces the arg-max by the sampling of
+    ``:147``.  Returns (sequences, [logits per kept step], [rows per kept step])."""
     active = [[bos] for _ in range(B)]
     idx = np.arange(B)
     finished = [None] * B
@@ -329,7 +339,10 @@ def greedy_decode(sess, B, max_len, bos, eos, keep_logits=0):
         if t < keep_logits:
             logs.append(logits.copy())
             rows.append(idx.copy())
-        nxt = argmax_rows(logits)
+        if sample is None:
+            nxt = argmax_rows(logits)
+        else:  # sample = (temperature, seed): Gumbel-max draw keyed by the original sentence index
+            nxt = sample_rows(logits, sample[0], sample[1], t, idx)
         done = nxt == eos
         for i, row in enumerate(idx):
             if done[i]:

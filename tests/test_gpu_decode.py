@@ -228,3 +228,24 @@ def test_stack_finished_and_errors(T):
         state_for(T, fx, model, vocab, sample_type='nucleus').inference()
     with pytest.raises(ValueError):
         state_for(T, fx, model, vocab, beam_size=9).inference()
+
+
+def test_sampling_decode_matches_oracle_draw_for_draw(T):
+    """The prod caller's mode (/root/reference/src/prod/dialog_model.py:108-120): stateful RNNLM, temperature
+    sampling, bos = eos = '|'.  Sampling is random in the reference; here the draws come from a counter-based
+    generator, so the oracle reproduces them exactly, and the oracle's sampler is pinned to the Categorical
+    distribution on the CPU."""
+    fx = load_fixture('rnnlm_stateful')
+    tmodel, model, vocab = native_models(T, fx['config'])
+    st = state_for(T, fx, model, vocab, sample_type='sample', temperature=0.8, seed=99, max_len=20)
+    got = seqs_of(st.inference())
+    sess = C.CanonGRUDecoder(tmodel).session(fx['z'])
+    want, _, _ = C.greedy_decode(sess, fx['z'].shape[1], 20, vocab.stoi['|'], vocab.stoi['|'], sample=(0.8, 99))
+    assert got == want
+    other = seqs_of(state_for(T, fx, model, vocab, sample_type='sample', temperature=0.8, seed=100, max_len=20).inference())
+    assert other != got
+    torch.manual_seed(5)
+    a = seqs_of(state_for(T, fx, model, vocab, sample_type='sample', max_len=20).inference())
+    torch.manual_seed(5)
+    b = seqs_of(state_for(T, fx, model, vocab, sample_type='sample', max_len=20).inference())
+    assert a == b                                   # torch.manual_seed governs the default seed

@@ -188,3 +188,14 @@ def test_logsoftmax_topk_unaligned_rows(K):
     tok = torch.empty(R, dtype=torch.int32, device='cuda')
     K.argmax_rows(xd, R, V, tok)
     assert np.array_equal(tok.cpu().numpy(), x.argmax(1))
+
+
+@pytest.mark.parametrize('V,temp', [(50, 1.0), (1000, 0.7), (32000, 1.3)])
+def test_sample_rows_bit_exact(K, V, temp):
+    r = rs(V)
+    R = 40
+    x = (r.standard_normal((R, V)) * 2).astype(np.float32)
+    sent = r.permutation(1000)[:R].astype(np.int32)
+    tok = torch.empty(R, dtype=torch.int32, device='cuda')
+    K.sample_rows(dev(x), R, V, temp, 1234, 7, dev(sent), tok)
+    assert np.array_equal(tok.cpu().numpy(), C.sample_rows(x, temp, 1234, 7, sent))

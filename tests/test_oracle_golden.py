@@ -99,3 +99,22 @@ def test_canonical_encoder_close_to_torch():
     valid = fx['enc_mask'][:, 0, :]
     ok, err = logits_close(encs[valid], fx['encs'][valid])
     assert ok, err
+
+
+def test_sampler_follows_the_categorical_distribution():
+    """``sample_type='sample'`` (/root/reference/src/inference.py:147) has no fixed output; the oracle's
+    Gumbel-max sampler is pinned to it in distribution: chi-square of 200k draws against softmax(x / T)."""
+    rs = np.random.RandomState(3)
+    V, n = 12, 200000
+    x = (rs.standard_normal(V) * 1.5).astype(np.float32)
+    for temp in (1.0, 0.5):
+        p = np.exp(x.astype(np.float64) / temp)
+        p /= p.sum()
+        draws = C.sample_rows(np.tile(x, (n, 1)), temp, seed=11, step=4, sent=np.arange(n))
+        counts = np.bincount(draws, minlength=V)
+        chi2 = ((counts - n * p) ** 2 / (n * p)).sum()
+        assert chi2 < 45.0, (temp, chi2)      # 11 degrees of freedom: P(chi2 > 45) < 1e-5
+    a = C.sample_rows(np.tile(x, (50, 1)), 1.0, seed=1, step=0, sent=np.arange(50))
+    b = C.sample_rows(np.tile(x, (50, 1))[::-1].copy(), 1.0, seed=1, step=0, sent=np.arange(50)[::-1].copy())
+    assert np.array_equal(a, b[::-1])         # a sentence's draw does not depend on its row in the batch
+    assert not np.array_equal(a, C.sample_rows(np.tile(x, (50, 1)), 1.0, seed=2, step=0, sent=np.arange(50)))

@@ -33,6 +33,7 @@ _PROTOS = {
     'tst_gru_cell_step_f32': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_gather_rows_f32': ([c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_argmax_rows_f32': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_vp], c_int),
+    'tst_sample_rows_f32': ([c_vp, c_i64, c_i64, c_i64, c_f32, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp, c_vp], c_int),
     'tst_logsoftmax_topk_f32': ([c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp], c_int),
     'tst_beam_merge': ([ctypes.POINTER(TstRows), c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                         c_vp], c_int),

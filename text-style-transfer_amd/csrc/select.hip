@@ -63,6 +63,39 @@ __global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restric
     if (threadIdx.x == 0) tok[blockIdx.x] = bi == INT_MAX ? 0 : bi;
 }
 
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+// Gumbel-max sampling: argmax_v (x_v / temperature - log(-log(u_v))), u_v from a counter-based hash of
+// (seed, step, sentence, v); first maximal index wins.  One workgroup per row.
+__global__ __launch_bounds__(256) void sample_rows_kernel(const float* __restrict__ x, int64_t ld, int V, float temperature,
+                                                          uint32_t seed, uint32_t step, const int32_t* __restrict__ sent,
+                                                          int32_t* __restrict__ tok, int vec_ok) {
+    __shared__ float red_v[4];
+    __shared__ int red_i[4];
+    const float* xr = x + (int64_t)blockIdx.x * ld;
+    const uint32_t rowkey = mix32((uint32_t)sent[blockIdx.x] * 0x9E3779B9u + mix32(step * 0x85EBCA6Bu + seed));
+    const int nch = (V + 3) >> 2;
+    float bv = -INFINITY;
+    int bi = INT_MAX;
+    for (int c = threadIdx.x; c < nch; c += 256) {
+        const float4 v = load_chunk(xr, c, V, vec_ok != 0);
+        const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int id = 4 * c + q;
+            const uint32_t h = mix32((uint32_t)id ^ rowkey);
+            const float u = (float)(h >> 9) * 1.1920928955078125e-07f + 5.9604644775390625e-08f;
+            const float key = e[q] / temperature + (-d_log(-d_log(u)));
+            if (id < V && key > bv) { bv = key; bi = id; }
+        }
+    }
+    block_argmax(bv, bi, red_v, red_i);
+    if (threadIdx.x == 0) tok[blockIdx.x] = bi == INT_MAX ? 0 : bi;
+}
+
 constexpr int MAXC = 32;    // resident chunks per thread: rows of up to 256 * 32 * 4 = 32768 floats stay in registers
 constexpr int CAND_CAP = 1024;  // LDS candidate list of the top-k filter
 
@@ -375,6 +408,17 @@ extern "C" int tst_argmax_rows_f32(const float* logits, int64_t ld, int64_t R, i
     hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, ld, (int)V, tok,
                        row_vec_ok(logits, ld));
     return tst_after_launch("tst_argmax_rows_f32");
+}
+
+extern "C" int tst_sample_rows_f32(const float* logits, int64_t ld, int64_t R, int64_t V, float temperature, uint32_t seed,
+                                   uint32_t step, const int32_t* sent, int32_t* tok, void* stream) {
+    TST_REQUIRE(logits && sent && tok, TST_ERR_ARG, "tst_sample_rows_f32: null pointer");
+    TST_REQUIRE(R >= 0 && V > 0 && ld >= V && V < (1ll << 30) && R < (1ll << 31) && temperature > 0.0f, TST_ERR_ARG,
+                "tst_sample_rows_f32: bad sizes or temperature <= 0");
+    if (R == 0) return TST_OK;
+    hipLaunchKernelGGL(sample_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, ld, (int)V,
+                       temperature, seed, step, sent, tok, row_vec_ok(logits, ld));
+    return tst_after_launch("tst_sample_rows_f32");
 }
 
 extern "C" int tst_logsoftmax_topk_f32(const float* logits, int64_t ld, int64_t R, int64_t V, int64_t k, float* top_val,

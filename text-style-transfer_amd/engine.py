@@ -23,13 +23,16 @@ def length_penalty_table(max_len, alpha):
 
 
 class DecodeLoop:
-    def __init__(self, session, n_sent, beam, max_len, bos, eos, pad, alpha=0.0, device=None):
+    def __init__(self, session, n_sent, beam, max_len, bos, eos, pad, alpha=0.0, device=None, sample=None):
         if not (1 <= beam <= 8):
             raise ValueError('beam_size must be in 1..8')
         if beam > session.V:
             raise ValueError('beam_size larger than the vocabulary')
         self.s, self.B, self.k, self.T = session, n_sent, beam, max_len
         self.bos, self.eos = int(bos), int(eos)
+        self.sample = sample  # None (arg-max) or (temperature, seed): Gumbel-max sampling, beam 1 only
+        if sample is not None and beam != 1:
+            raise ValueError('sampling and beam search cannot be combined')
         # with no length penalty a finished top beam is final (see tst_retire_compact): end the sentence there
         self.top_ends = beam > 1 and float(alpha) == 0.0
         dev = device or torch.device('cuda', torch.cuda.current_device())
@@ -73,7 +76,10 @@ class DecodeLoop:
             if t < keep_logits:
                 self.kept.append((logits[:R, :s.V].clone(), self.cur.sent[:R].clone(), self.cur.fin[:R].clone()))
             if k == 1:
-                K.argmax_rows(logits, R, s.V, self.am)
+                if self.sample is None:
+                    K.argmax_rows(logits, R, s.V, self.am)
+                else:
+                    K.sample_rows(logits, R, s.V, self.sample[0], self.sample[1], t, self.cur.sent, self.am)
                 K.greedy_select(self.am, R, self.eos, self.sel, self.cur)
             else:
                 K.logsoftmax_topk(logits, R, s.V, k, self.top_val, self.top_idx, self.lse)

@@ -8,7 +8,9 @@ kernels on device-resident state (``engine.DecodeLoop``), and models of this pac
 incrementally (KV cache / carried GRU state) instead of being re-run on the whole prefix (``:132``).
 
 Additive keys (not in the reference): ``beam_size`` (1 = the reference's greedy arg-max; the reference
-has no beam search), ``length_penalty`` (alpha of ((5 + n) / 6) ** alpha, used to rank finished beams).
+has no beam search), ``length_penalty`` (alpha of ((5 + n) / 6) ** alpha, used to rank finished beams),
+``seed`` (makes ``sample_type='sample'`` reproducible; by default a seed is drawn from torch's generator,
+so ``torch.manual_seed`` governs it like it governs the reference's ``Categorical.sample``).
 
 Any other callable works as ``model`` too (the reference's protocol ``model(inputs, active_seqs, *args,
 **kwargs) -> [B, t, V]`` or ``(logits, new_inputs)`` with ``substitute_inputs``); it is then called once
@@ -84,6 +86,7 @@ class InferenceState:
         # Additive keys
         self.beam_size = state_dict.get('beam_size', 1)
         self.length_penalty = state_dict.get('length_penalty', 0.0)
+        self.seed = state_dict.get('seed')  # sampling only; default: drawn from torch's global generator
 
         self.finished = [None for _ in range(self.batch_size)]
         self.num_steps_done = 0
@@ -106,10 +109,14 @@ class InferenceState:
                               self.inputs_batch_dim, self.beam_size, len(self.vocab))
 
     def inference(self, keep_logits=0):
-        if self.sample_type != 'max':
-            if self.sample_type == 'sample':
-                raise NotImplementedError("sample_type='sample' is not available in this build yet")
+        if self.sample_type not in ('max', 'sample'):
             raise NotImplementedError  # as /root/reference/src/inference.py:149
+        sample = None
+        if self.sample_type == 'sample':
+            if self.beam_size != 1:
+                raise ValueError("sample_type='sample' needs beam_size 1")
+            seed = self.seed if self.seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+            sample = (float(self.temperature), seed)
         if self.gumbel:
             raise NotImplementedError('gumbel decoding is not available in this build yet')
         if self.active_seqs is not None:
@@ -119,7 +126,7 @@ class InferenceState:
         device = self.inputs.device if self.inputs.is_cuda else torch.device('cuda', torch.cuda.current_device())
         with torch.cuda.device(device):
             loop = DecodeLoop(self._session(), self.batch_size, self.beam_size, self.max_len, self.bos_idx,
-                              self.eos_idx, self.pad_idx, self.length_penalty, device)
+                              self.eos_idx, self.pad_idx, self.length_penalty, device, sample)
             out_tok, out_len, out_score = loop.run(keep_logits)
             self.loop = loop
             self.num_steps_done = loop.steps_done

@@ -90,6 +90,13 @@ def argmax_rows(logits, n_rows, n_cols, out_tok):
     call('tst_argmax_rows_f32', _p(logits), logits.stride(0), n_rows, n_cols, _p(out_tok), _stream())
 
 
+def sample_rows(logits, n_rows, n_cols, temperature, seed, step, sent, out_tok):
+    _chk(out_tok, torch.int32, 'out_tok'); _chk(sent, torch.int32, 'sent')
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.stride(-1) == 1
+    call('tst_sample_rows_f32', _p(logits), logits.stride(0), n_rows, n_cols, float(temperature), int(seed) & 0xffffffff,
+         int(step), _p(sent), _p(out_tok), _stream())
+
+
 def logsoftmax_topk(logits, n_rows, n_cols, k, top_val, top_idx, lse):
     _chk(top_val, torch.float32, 'top_val'); _chk(top_idx, torch.int32, 'top_idx'); _chk(lse, torch.float32, 'lse')
     assert logits.is_cuda and logits.dtype == torch.float32 and logits.stride(-1) == 1
