@@ -182,9 +182,44 @@ def stateful_case(InferenceState, name, H, V, n_layers, B, max_len, eos_bias, ou
     save(name, config, {'z': z.numpy()}, seqs, rec, finished_lens_of(seqs, max_len))
 
 
+def postprocess_case():
+    """Outputs of the reference's own ``itos_many`` and ``compute_bleu_for_sents`` on synthetic sentences."""
+    from src.utils.data_utils import itos_many
+    from src.losses.bleu import compute_bleu, compute_bleu_for_sents
+    rs = np.random.RandomState(7)
+    words = ['<unk>', '<pad>', '<bos>', '<eos>'] + ['tok%d' % i for i in range(20)] + ['ab@@', 'cd@@', 'ef']
+    vocab = R.RefVocab(words[4:])
+    seqs = []
+    for _ in range(12):
+        n = rs.randint(0, 9)
+        body = rs.randint(4, len(vocab), size=n).tolist()
+        seqs.append([2] + body + ([3] if rs.rand() < 0.5 else []) + [1] * rs.randint(0, 3))
+    cases = {'vocab': vocab.itos, 'seqs': seqs, 'itos_default': itos_many(seqs, vocab),
+             'itos_keep_special': itos_many(seqs, vocab, remove_special=False), 'itos_chars': itos_many(seqs, vocab, sep='')}
+    hyps, refs = [], []
+    for _ in range(10):
+        n = rs.randint(1, 12)
+        ref = ['w%d' % i for i in rs.randint(0, 6, size=n)]
+        hyp = [w if rs.rand() < 0.7 else 'w%d' % rs.randint(0, 6) for w in ref][:rs.randint(1, n + 1)] + \
+              ['w%d' % i for i in rs.randint(0, 6, size=rs.randint(0, 3))]
+        hyps.append(' '.join(hyp))
+        refs.append(' '.join(ref))
+    cases['bleu'] = dict(hyps=hyps, refs=refs, plain=compute_bleu_for_sents(hyps, refs),
+                         smooth=compute_bleu_for_sents(hyps, refs, smooth=True),
+                         order2=compute_bleu_for_sents(hyps, refs, max_order=2),
+                         full=list(compute_bleu([[r.split()] for r in refs], [h.split() for h in hyps])),
+                         per_sentence=[compute_bleu_for_sents([h], [r], smooth=True) for h, r in zip(hyps, refs)],
+                         multi_ref=list(compute_bleu([[refs[0].split(), refs[1].split()], [refs[2].split()]],
+                                                     [hyps[0].split(), hyps[2].split()])))
+    with open(os.path.join(HERE, 'postprocess.json'), 'w') as f:
+        json.dump(cases, f, indent=1)
+    print('postprocess      bleu=%.4f smooth=%.4f' % (cases['bleu']['plain'], cases['bleu']['smooth']))
+
+
 def main():
     torch.set_num_threads(4)
     InferenceState, simple_inference = import_reference()
+    postprocess_case()
     m, v, e, mk = transformer_case(InferenceState, 'tfm_v64', V=64, B=6, S_max=12, max_len=16, eos_bias=1.5,
                                    out_scale=2.0, seed=101, through_encoder=False)
     base = dict(kind='transformer', V=64, hp=dict(R.mt_hp()), weight_seed=42, eos_bias=0.25, out_scale=2.0)

@@ -11,6 +11,8 @@ from .inference import InferenceState, simple_inference
 from .transformer import HP, Transformer, TransformerDecoder
 from .encoder import TransformerEncoder
 from .rnn import RNNDecoder, RNNLM
+from .postprocess import itos_many, compute_bleu_for_sents, corpus_bleu
 
 __all__ = ['InferenceState', 'simple_inference', 'Vocab', 'HP', 'Transformer', 'TransformerDecoder',
-           'TransformerEncoder', 'RNNDecoder', 'RNNLM', 'TstError', 'version']
+           'TransformerEncoder', 'RNNDecoder', 'RNNLM', 'itos_many', 'compute_bleu_for_sents', 'corpus_bleu', 'TstError',
+           'version']
