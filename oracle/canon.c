@@ -234,19 +234,42 @@ void orc_argmax_rows(const float* x, int64_t ld, int64_t R, int64_t V, int32_t* 
     }
 }
 
-/* per row: lse = max + log(sum exp(x - max)) with 256 partial sums (element v -> partial (v / 4) % 256,
- * v ascending) + butterfly; and the k largest logits (value desc, index asc). */
+/* per row: lse = log sum exp(x), computed in one pass by 256 interleaved partial states (m_l, s_l).
+ * Chunk c = elements 4c..4c+3 (elements beyond V count as -inf).  Partial l consumes its chunks
+ * l, l + 256, l + 512, ... in groups of four: with the group's 16 values x_0..x_15 in ascending index order
+ *   m' = max(m, x_0..x_15);  s = s * exp(m - m');  s += exp(x_0 - m'); ...; s += exp(x_15 - m');  m = m'.
+ * Then M = max_l m_l, t_l = s_l * exp(m_l - M), total = butterfly sum of the t_l (64-groups, then groups
+ * left to right), lse = M + log(total).
+ * And the k largest logits (value desc, index asc). */
 void orc_logsoftmax_topk(const float* x, int64_t ld, int64_t R, int64_t V, int k, float* top_val, int32_t* top_idx,
                          float* lse) {
 #pragma omp parallel for
     for (int64_t r = 0; r < R; ++r) {
         const float* xr = x + r * ld;
-        float mx = xr[0];
-        for (int64_t v = 1; v < V; ++v) if (xr[v] > mx) mx = xr[v];
+        float pm[256], ps[256];
+        for (int l = 0; l < 256; ++l) { pm[l] = -INFINITY; ps[l] = 0.0f; }
+        int64_t nch = (V + 3) / 4;
+        for (int64_t c0 = 0; c0 < nch; c0 += 1024) {          /* one group per partial and iteration */
+            for (int l = 0; l < 256 && c0 + l < nch; ++l) {
+                float e[16];
+                for (int u = 0; u < 4; ++u)
+                    for (int q = 0; q < 4; ++q) {
+                        int64_t idx = 4 * (c0 + l + 256 * u) + q;
+                        e[4 * u + q] = idx < V ? xr[idx] : -INFINITY;
+                    }
+                float mn = pm[l];
+                for (int i = 0; i < 16; ++i) mn = fmaxf(mn, e[i]);
+                float sacc = ps[l] * orc_exp(pm[l] - mn);
+                for (int i = 0; i < 16; ++i) sacc = sacc + orc_exp(e[i] - mn);
+                ps[l] = sacc;
+                pm[l] = mn;
+            }
+        }
+        float M = pm[0];
+        for (int l = 1; l < 256; ++l) if (pm[l] > M) M = pm[l];
         float p[256];
-        for (int l = 0; l < 256; ++l) p[l] = 0.0f;
-        for (int64_t v = 0; v < V; ++v) { int l = (int)((v >> 2) & 255); p[l] = p[l] + orc_exp(xr[v] - mx); }
-        lse[r] = mx + orc_log(sum_butterfly(p, 256));
+        for (int l = 0; l < 256; ++l) p[l] = ps[l] * orc_exp(pm[l] - M);
+        lse[r] = M + orc_log(sum_butterfly(p, 256));
         for (int j = 0; j < k; ++j) { top_val[r * k + j] = -INFINITY; top_idx[r * k + j] = -1; }
         for (int64_t v = 0; v < V; ++v) {
             float xv = xr[v];

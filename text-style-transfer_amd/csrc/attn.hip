@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
 #pragma unroll
     for (int i = 0; i < MAXP / 64; ++i) {
         const int p = lane + 64 * i;
-        const float e = p < n ? d_exp(s[i] - m) : 0.0f;
+        const float e = p < n ? d_exp_le0(s[i] - m) : 0.0f;
         s[i] = e;
         part = part + e;
     }

@@ -7,7 +7,7 @@
 // 64 x 64 x 16 tiles (one MFMA tile per wave) so that every CU gets work.  A and Wt tiles are
 // staged through registers into k-major LDS images ([k][m] and [k][n]) so that the one-float-per-lane
 // MFMA operands are conflict-free ds_read_b32; global loads of tile t+1 are in flight while tile t is
-// multiplied (two LDS buffers, one barrier per tile).  Workgroups are renumbered so that each XCD
+// multiplied (three LDS buffers, one barrier per tile, taken in the middle of the tile's MFMAs).  Workgroups are renumbered so that each XCD
 // walks a contiguous, m-grouped range of tiles and re-reads A / Wt panels from its own L2.
 #include "tst_common.h"
 
@@ -26,8 +26,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                                                        float* C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
     constexpr int BM = 64 * WT, BN = 64 * WT, LDT = BM + 4;
     constexpr int NLD = WT;  // float4 loads per thread and operand: BM * BK / 4 / 256
-    __shared__ __attribute__((aligned(16))) float As[2][BK][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][LDT];
+    __shared__ __attribute__((aligned(16))) float As[3][BK][LDT];
+    __shared__ __attribute__((aligned(16))) float Bs[3][BK][LDT];
 
     // workgroup id -> logical tile index: consecutive ids go to different XCDs, so give every XCD a
     // contiguous range (bijective for any grid size), then walk tiles in groups of GROUP_M rows.
@@ -100,56 +100,97 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
             for (int r = 0; r < 16; ++r) acc[i][j][r] = b;
     }
 
+    // Three LDS buffers; per k-tile: first half of the MFMAs, then the staged registers of tile t+1 go to
+    // LDS, the loads of tile t+2 are issued and the workgroup barrier is taken IN THE MIDDLE of the tile,
+    // then the second half.  A wave so reaches the barrier with MFMAs in flight and has half a tile of
+    // independent MFMAs right after it: the matrix pipe does not drain around the barrier.  The buffer
+    // written in tile t was last read in tile t-2, and every wave has passed the barrier of tile t-1 since.
     const int nkt = (K + BK - 1) / BK;
     TST_LOAD_TILE(0);
     TST_STORE_TILE(0);
+    if (nkt > 1) TST_LOAD_TILE(BK);
     __syncthreads();
     const int arow = wm * 32 * WT + (lane & 31), bcol = wn * 32 * WT + (lane & 31), khalf = lane >> 5;
+    // The MFMA operands (one float of A and of Wt per lane and 32 x 32 tile) are read from LDS one k-step
+    // ahead of the MFMAs that use them, also across the mid-tile barrier and into the next tile's buffer
+    // (complete since that barrier), so the LDS latency is never exposed.
+    float a_cur[WT], b_cur[WT], a_nxt[WT], b_nxt[WT];
+#define TST_READ_OPERANDS(av, bv, bufi, kk)                                                                   \
+    _Pragma("unroll") for (int i = 0; i < WT; ++i) {                                                          \
+        av[i] = As[bufi][(kk) + khalf][arow + 32 * i];                                                        \
+        bv[i] = Bs[bufi][(kk) + khalf][bcol + 32 * i];                                                        \
+    }
+    int buf = 0;
+    TST_READ_OPERANDS(a_cur, b_cur, buf, 0)
     for (int kt = 0; kt < nkt; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nkt) TST_LOAD_TILE((kt + 1) * BK);
+        const int nbuf = buf == 2 ? 0 : buf + 1;
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
-            const int kr = kk + khalf;
-            float av[WT], bv[WT];
-#pragma unroll
-            for (int i = 0; i < WT; ++i) {
-                av[i] = As[buf][kr][arow + 32 * i];
-                bv[i] = Bs[buf][kr][bcol + 32 * i];
+            if (kk + 2 < BK) {
+                TST_READ_OPERANDS(a_nxt, b_nxt, buf, kk + 2)
+            } else if (kt + 1 < nkt) {
+                TST_READ_OPERANDS(a_nxt, b_nxt, nbuf, 0)
             }
 #pragma unroll
             for (int i = 0; i < WT; ++i)
 #pragma unroll
                 for (int j = 0; j < WT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < WT; ++i) { a_cur[i] = a_nxt[i]; b_cur[i] = b_nxt[i]; }
+            if (kk == BK / 2 - 2) {
+                if (kt + 1 < nkt) {
+                    TST_STORE_TILE(nbuf);
+                    if (kt + 2 < nkt) TST_LOAD_TILE((kt + 2) * BK);
+                }
+                __syncthreads();
+            }
         }
-        if (kt + 1 < nkt) TST_STORE_TILE(buf ^ 1);
-        __syncthreads();
+        buf = nbuf;
     }
+#undef TST_READ_OPERANDS
 
-    // epilogue: lane owns column col of 16 rows per 32 x 32 tile (rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
+    // epilogue: lane owns column col of 16 rows per 32 x 32 tile (rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
+    // tiles that lie fully inside the matrix take the unguarded path
+    const bool full_tile = m0 + BM <= M && n0 + BN <= N;
 #pragma unroll
     for (int i = 0; i < WT; ++i)
 #pragma unroll
         for (int j = 0; j < WT; ++j) {
             const int col = n0 + wn * 32 * WT + j * 32 + (lane & 31);
             const int row0 = m0 + wm * 32 * WT + i * 32 + 4 * (lane >> 5);
-            const bool col_ok = col < N;
             float rv[16];
-            if (HAS_RES) {
+            if (full_tile) {
+                float* cp = C + (int64_t)row0 * ldc + col;
+                if (HAS_RES) {
+                    const float* rp = res + (int64_t)row0 * ldr + col;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) rv[r] = rp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldr];
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float v = acc[i][j][r];
+                    if (RELU) v = v > 0.0f ? v : 0.0f;
+                    if (HAS_RES) v = v + rv[r];
+                    cp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = v;
+                }
+            } else {
+                const bool col_ok = col < N;
+                if (HAS_RES) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row0 + (r & 3) + 8 * (r >> 2);
+                        rv[r] = (col_ok && row < M) ? res[(int64_t)row * ldr + col] : 0.0f;
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = row0 + (r & 3) + 8 * (r >> 2);
-                    rv[r] = (col_ok && row < M) ? res[(int64_t)row * ldr + col] : 0.0f;
+                    float v = acc[i][j][r];
+                    if (RELU) v = v > 0.0f ? v : 0.0f;
+                    if (HAS_RES) v = v + rv[r];
+                    if (col_ok && row < M) C[(int64_t)row * ldc + col] = v;
                 }
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + (r & 3) + 8 * (r >> 2);
-                float v = acc[i][j][r];
-                if (RELU) v = v > 0.0f ? v : 0.0f;
-                if (HAS_RES) v = v + rv[r];
-                if (col_ok && row < M) C[(int64_t)row * ldc + col] = v;
             }
         }
 }

@@ -96,22 +96,39 @@ __global__ __launch_bounds__(256) void sample_rows_kernel(const float* __restric
     if (threadIdx.x == 0) tok[blockIdx.x] = bi == INT_MAX ? 0 : bi;
 }
 
-constexpr int MAXC = 32;    // resident chunks per thread: rows of up to 256 * 32 * 4 = 32768 floats stay in registers
 constexpr int CAND_CAP = 1024;  // LDS candidate list of the top-k filter
 
-// One workgroup per row; thread t owns the float4 chunks t, t + 256, ... of the row.
-//  pass A  row maximum m, and tau = the K-th largest of the 256 per-thread maxima: at least K elements
-//          are >= tau, so the K largest elements of the row are all >= tau.
-//  pass B  sum of exp(x - m) per thread in ascending element order (wave butterfly, then the four waves
-//          left to right), while elements >= tau go to a candidate list in LDS (normally ~K entries).
-//  select  K rounds of workgroup arg-max over the candidates, (value desc, index asc).  If the list
-//          overflows (many equal values), K rounds over the whole row instead: each round takes the best
-//          element after the previous winner in that order.
-// The row is read from HBM once when it fits the registers (RESIDENT), otherwise re-read per pass.
-template <int K, bool RESIDENT>
+// online log-sum-exp update with a group of 16 values (ascending index order)
+__device__ __forceinline__ void lse_consume(const float4 (&vv)[4], float& m, float& sacc) {
+    float mn = m;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) mn = fmaxf(fmaxf(fmaxf(mn, vv[u].x), fmaxf(vv[u].y, vv[u].z)), vv[u].w);
+    sacc = sacc * d_exp_le0(m - mn);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        sacc = sacc + d_exp_le0(vv[u].x - mn);
+        sacc = sacc + d_exp_le0(vv[u].y - mn);
+        sacc = sacc + d_exp_le0(vv[u].z - mn);
+        sacc = sacc + d_exp_le0(vv[u].w - mn);
+    }
+    m = mn;
+}
+
+// One workgroup per row, ONE pass over the row: each logit is read from HBM once and only a few registers
+// are live, so occupancy is high and the loads overlap the arithmetic.  Thread t owns the float4 chunks
+// t, t + 256, ... and consumes them four at a time (16 values x_i, ascending index) into an online
+// log-sum-exp state:  m' = max(m, x_i);  s = s * exp(m - m') + sum_i exp(x_i - m');  m = m'.
+// Then M = max of the 256 m, total = butterfly sum of s * exp(m - M) (wave butterfly, waves left to right),
+// lse = M + log(total).
+// Top K: m is also the thread's largest element.  tau = the K-th largest of the 256 thread maxima (K rounds
+// of workgroup arg-max); at least K elements are >= tau and they can only sit in threads whose own maximum
+// is >= tau, so only those (about K) threads re-read their chunks and push elements >= tau to an LDS list,
+// from which K more rounds pick the result (value desc, index asc).  If the list overflows (many equal
+// values) the K rounds run over the whole row instead.
+template <int K, bool VEC>
 __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __restrict__ x, int64_t ld, int V,
                                                               float* __restrict__ top_val, int32_t* __restrict__ top_idx,
-                                                              float* __restrict__ lse, int vec_ok) {
+                                                              float* __restrict__ lse) {
     __shared__ float red_v[4];
     __shared__ int red_i[4];
     __shared__ float red_s[4];
@@ -122,72 +139,55 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __res
     const int64_t r = blockIdx.x;
     const float* xr = x + r * ld;
     const int nch = (V + 3) >> 2;
-    const bool vok = vec_ok != 0;
-    float4 buf[RESIDENT ? MAXC : 1];
     if (t == 0) cand_n = 0;
-
-    float tmax = -INFINITY;
-    if (RESIDENT) {
+    float m = -INFINITY, sacc = 0.0f;
+    // a chunk beyond the row reads as -inf and contributes exp(-inf) = 0
+    int c0 = t;
+    if (VEC) {  // groups that lie fully inside the row: unguarded 16-byte loads
+        const int nfull = V >> 2;
+        for (; c0 + 768 < nfull; c0 += 1024) {
+            float4 vv[4];
 #pragma unroll
-        for (int i = 0; i < MAXC; ++i) {
-            const int c = t + 256 * i;
-            float4 v = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-            if (c < nch) v = load_chunk(xr, c, V, vok);
-            buf[i] = v;
-            tmax = fmaxf(tmax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
-        }
-    } else {
-        for (int c = t; c < nch; c += 256) {
-            const float4 v = load_chunk(xr, c, V, vok);
-            tmax = fmaxf(tmax, fmaxf(fmaxf(v.x, v.y), fmaxf(v.z, v.w)));
+            for (int u = 0; u < 4; ++u) vv[u] = reinterpret_cast<const float4*>(xr)[c0 + 256 * u];
+            lse_consume(vv, m, sacc);
         }
     }
-    float m = -INFINITY, tau = -INFINITY;
+    for (; c0 < nch; c0 += 1024) {  // ragged end of the row (and rows that are not 16-byte aligned)
+        float4 vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) vv[u] = load_chunk(xr, c0 + 256 * u, V, VEC);
+        lse_consume(vv, m, sacc);
+    }
+    // K-th largest thread maximum (ties between threads: lower thread first)
+    float M = -INFINITY, tau = -INFINITY, cand = m;
     for (int o = 0; o < K; ++o) {
-        float v = tmax;
+        float v = cand;
         int id = t;
         block_argmax(v, id, red_v, red_i);
-        if (o == 0) m = v;
+        if (o == 0) M = v;
         tau = v;
-        if (id == t) tmax = -INFINITY;
+        if (id == t) cand = -INFINITY;
     }
-
-    float part = 0.0f;
-#define TST_PASS_B(v, c)                                                                        \
-    do {                                                                                        \
-        part = part + d_exp((v).x - m);                                                         \
-        part = part + d_exp((v).y - m);                                                         \
-        part = part + d_exp((v).z - m);                                                         \
-        part = part + d_exp((v).w - m);                                                         \
-        const float e_[4] = {(v).x, (v).y, (v).z, (v).w};                                       \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_)                                        \
-            if (e_[q_] >= tau && 4 * (c) + q_ < V) {                                            \
-                const int at_ = atomicAdd(&cand_n, 1);                                          \
-                if (at_ < CAND_CAP) { cand_v[at_] = e_[q_]; cand_i[at_] = 4 * (c) + q_; }       \
-            }                                                                                   \
-    } while (0)
-    if (RESIDENT) {
-#pragma unroll
-        for (int i = 0; i < MAXC; ++i) {
-            const int c = t + 256 * i;
-            if (c < nch) TST_PASS_B(buf[i], c);
-        }
-    } else {
-        for (int c = t; c < nch; c += 256) {
-            const float4 v = load_chunk(xr, c, V, vok);
-            TST_PASS_B(v, c);
-        }
-    }
-#undef TST_PASS_B
-    part = wave_sum_butterfly(part);
+    float part = wave_sum_butterfly(sacc * d_exp_le0(m - M));
     if ((t & 63) == 0) red_s[t >> 6] = part;
+    if (m >= tau) {  // about K threads
+        for (int c = t; c < nch; c += 256) {
+            const float4 v = load_chunk(xr, c, V, VEC);
+            const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (e[q] >= tau && 4 * c + q < V) {
+                    const int at = atomicAdd(&cand_n, 1);
+                    if (at < CAND_CAP) { cand_v[at] = e[q]; cand_i[at] = 4 * c + q; }
+                }
+        }
+    }
     __syncthreads();
     if (t == 0) {
         const float total = ((red_s[0] + red_s[1]) + red_s[2]) + red_s[3];
-        lse[r] = m + d_log(total);
+        lse[r] = M + d_log(total);
     }
     const int ncand = cand_n;
-
     if (ncand <= CAND_CAP) {
         for (int o = 0; o < K; ++o) {
             float bv = -INFINITY;
@@ -205,20 +205,16 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __res
         for (int o = 0; o < K; ++o) {
             float bv = -INFINITY;
             int bi = INT_MAX;
-#define TST_SCAN(v, c)                                                                                  \
-    do {                                                                                                \
-        const float e_[4] = {(v).x, (v).y, (v).z, (v).w};                                               \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                                              \
-            const int id_ = 4 * (c) + q_;                                                               \
-            const bool after_ = e_[q_] < lastv || (e_[q_] == lastv && id_ > lasti);                     \
-            if (id_ < V && after_ && better(e_[q_], id_, bv, bi)) { bv = e_[q_]; bi = id_; }            \
-        }                                                                                               \
-    } while (0)
-            for (int c = t; c < nch; c += 256) {  // rare path: re-read the row instead of keeping it live
-                const float4 v = load_chunk(xr, c, V, vok);
-                TST_SCAN(v, c);
+            for (int c = t; c < nch; c += 256) {
+                const float4 v = load_chunk(xr, c, V, VEC);
+                const float e[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int id = 4 * c + q;
+                    const bool after = e[q] < lastv || (e[q] == lastv && id > lasti);
+                    if (id < V && after && better(e[q], id, bv, bi)) { bv = e[q]; bi = id; }
+                }
             }
-#undef TST_SCAN
             block_argmax(bv, bi, red_v, red_i);
             lastv = bv; lasti = bi;
             if (t == 0) { top_val[r * K + o] = bv; top_idx[r * K + o] = bi == INT_MAX ? -1 : bi; }
@@ -385,13 +381,10 @@ inline int row_vec_ok(const float* x, int64_t ld) { return (tst_aligned16(x) && 
 
 template <int K>
 int launch_topk(const float* logits, int64_t ld, int64_t R, int64_t V, float* tv, int32_t* ti, float* lse, hipStream_t st) {
-    const int vec_ok = row_vec_ok(logits, ld);
-    if (V <= 256 * MAXC * 4)
-        hipLaunchKernelGGL((logsoftmax_topk_kernel<K, true>), dim3((unsigned)R), dim3(256), 0, st, logits, ld, (int)V, tv, ti,
-                           lse, vec_ok);
+    if (row_vec_ok(logits, ld))
+        hipLaunchKernelGGL((logsoftmax_topk_kernel<K, true>), dim3((unsigned)R), dim3(256), 0, st, logits, ld, (int)V, tv, ti, lse);
     else
-        hipLaunchKernelGGL((logsoftmax_topk_kernel<K, false>), dim3((unsigned)R), dim3(256), 0, st, logits, ld, (int)V, tv,
-                           ti, lse, vec_ok);
+        hipLaunchKernelGGL((logsoftmax_topk_kernel<K, false>), dim3((unsigned)R), dim3(256), 0, st, logits, ld, (int)V, tv, ti, lse);
     return tst_after_launch("tst_logsoftmax_topk_f32");
 }
 

@@ -50,11 +50,17 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-__device__ __forceinline__ float d_exp(float x) {
-    if (!(x >= -87.0f)) return 0.0f;
-    if (x > 88.0f) x = 88.0f;
-    float n = rintf(x * 1.44269504088896341f);
-    float r = __builtin_fmaf(n, -0.693145751953125f, x);
+// exp(x): 0 for x < -87 (and for NaN), x clamped to 88 above.  Branch-free: the argument is clamped into
+// the polynomial's range and the out-of-range case is a select; 2^n is applied with ldexp, which gives the
+// same bits as multiplying by the float 2^n for every n in [-126, 127] (checked on the device over dense
+// ranges, results in the subnormal range included).
+template <bool UPPER_CLAMP>
+__device__ __forceinline__ float d_exp_impl(float x) {
+    const bool in_range = x >= -87.0f;
+    float xc = fmaxf(x, -87.0f);
+    if (UPPER_CLAMP) xc = fminf(xc, 88.0f);
+    const float n = rintf(xc * 1.44269504088896341f);
+    float r = __builtin_fmaf(n, -0.693145751953125f, xc);
     r = __builtin_fmaf(n, -1.42860682030941723212e-6f, r);
     float p = 1.9875691500e-4f;
     p = __builtin_fmaf(p, r, 1.3981999507e-3f);
@@ -62,10 +68,15 @@ __device__ __forceinline__ float d_exp(float x) {
     p = __builtin_fmaf(p, r, 4.1665795894e-2f);
     p = __builtin_fmaf(p, r, 1.6666665459e-1f);
     p = __builtin_fmaf(p, r, 5.0000001201e-1f);
-    float r2 = r * r;
-    float y = __builtin_fmaf(p, r2, r) + 1.0f;
-    return y * __uint_as_float((uint32_t)((int)n + 127) << 23);
+    const float r2 = r * r;
+    const float y = __builtin_fmaf(p, r2, r) + 1.0f;
+    const float v = ldexpf(y, (int)n);
+    return in_range ? v : 0.0f;
 }
+
+__device__ __forceinline__ float d_exp(float x) { return d_exp_impl<true>(x); }
+// for arguments known to be <= 0 (x - max): no upper clamp
+__device__ __forceinline__ float d_exp_le0(float x) { return d_exp_impl<false>(x); }
 
 __device__ __forceinline__ float d_log(float x) {
     uint32_t u = __float_as_uint(x);
