@@ -47,8 +47,8 @@ def decode_batch(model, vocab, src, beam, alpha):
     encs, enc_mask = model.encoder(src)
     st = tst_amd.InferenceState({'model': model.decoder, 'inputs': encs, 'enc_mask': enc_mask, 'vocab': vocab,
                                  'max_len': MAX_LEN, 'beam_size': beam, 'length_penalty': alpha})
-    st.inference()
-    return st.loop.out_tok, st.loop.out_len, st.loop
+    tok, lens, _ = st.decode_packed()   # device tensors; the per-sentence list of the reference API is not built
+    return tok, lens, st.loop
 
 
 def cpu_baseline(eos_bias, sample, seconds_cap=40.0):

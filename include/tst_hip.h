@@ -103,12 +103,14 @@ typedef struct tst_rows {
     int32_t* nemit;
 } tst_rows;
 
-/* Beam merge, one sentence per thread: every live beam offers its k best tokens with value
- * score + (top_val - lse), a finished beam offers itself unchanged, at step 0 only beam 0 offers; the k
- * best offers (ties: lower beam, then lower rank) become the new beams.  Writes, per new row slot:
- * parent (row index before the merge), tok, score, fin, nemit into sel_*. */
+/* Beam merge, one sentence per thread.  The sentence has k_in input rows (rows a*k_in .. a*k_in+k_in-1 of
+ * `cur`, top_val, top_idx [row][k] and lse) and gets k output slots (a*k .. a*k+k-1 of sel_*): every live input
+ * beam offers its k best tokens with value score + (top_val - lse), a finished beam offers itself unchanged;
+ * the k best offers (ties: lower beam, then lower rank) become the new beams in that order.  At the first
+ * step all beams of a sentence would be identical, so the caller runs one row per sentence (k_in = 1);
+ * afterwards k_in = k.  Writes per output slot: parent (input row index), tok, score, fin, nemit. */
 int tst_beam_merge(const tst_rows* cur, const float* top_val, const int32_t* top_idx, const float* lse, int64_t n_sent,
-                   int64_t k, int64_t step, int32_t eos, int32_t* sel_parent, int32_t* sel_tok, float* sel_score,
+                   int64_t k, int64_t k_in, int32_t eos, int32_t* sel_parent, int32_t* sel_tok, float* sel_score,
                    int32_t* sel_fin, int32_t* sel_nemit, void* stream);
 
 /* Greedy counterpart of tst_beam_merge (k = 1): parent = row, tok = argmax token, fin = (tok == eos). */

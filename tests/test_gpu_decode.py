@@ -149,8 +149,9 @@ def test_random_batch_bit_exact_vs_oracle(T, beam, alpha):
         # rows of the sentences still alive on the GPU (it may retire a sentence earlier than the oracle:
         # with no length penalty a finished top beam is final), beam by beam
         lg, sent, fin = (x.cpu().numpy() for x in st.loop.kept[i])
+        k_in = 1 if (i == 0 and beam > 1) else beam   # the GPU runs step 0 with one row per sentence
         first_row = {int(s): a * beam for a, s in enumerate(alive[i])}
-        orc_rows = np.array([first_row[int(s)] for s in sent[::beam]])[:, None] + np.arange(beam)[None]
+        orc_rows = np.array([first_row[int(s)] for s in sent[::k_in]])[:, None] + np.arange(k_in)[None]
         live = fin == 0
         assert np.array_equal(lg[live], logs[i][orc_rows.reshape(-1)][live])
 

@@ -113,6 +113,7 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
 #pragma unroll 4
         for (int p = 0; p < n; ++p) {
             const float wp = sc[w][p];
+            if (wp == 0.0f) continue;  // padding (or underflow): fma(0, v, acc) == acc; wave-uniform branch
             const float* vp = vrow(p) + c0;
             if (VEC == 4) {
                 const float4 v = *reinterpret_cast<const float4*>(vp);

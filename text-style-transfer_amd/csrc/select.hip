@@ -239,22 +239,21 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const int32_t* __res
 // which makes ties go to the lower beam, then the lower rank
 __global__ __launch_bounds__(256) void beam_merge_kernel(tst_rows cur, const float* __restrict__ top_val,
                                                          const int32_t* __restrict__ top_idx,
-                                                         const float* __restrict__ lse, int64_t n_sent, int k, int step,
+                                                         const float* __restrict__ lse, int64_t n_sent, int k, int k_in,
                                                          int32_t eos, int32_t* parent, int32_t* tok, float* score,
                                                          int32_t* fin, int32_t* nemit) {
     const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (a >= n_sent) return;
-    const int64_t base = a * k;
+    const int64_t base = a * k_in;   // input rows of the sentence
+    const int64_t obase = a * k;     // output slots
     float cv[64];
     int8_t cj[64];
     int32_t ct[64];
     int nc = 0;
-    for (int j = 0; j < k; ++j) {
+    for (int j = 0; j < k_in; ++j) {
         const int64_t row = base + j;
         if (cur.fin[row]) {
             cv[nc] = cur.score[row]; cj[nc] = (int8_t)j; ct[nc] = -1; ++nc;
-        } else if (step == 0 && j > 0) {
-            continue;
         } else {
             const float sc = cur.score[row], ls = lse[row];
             for (int rk = 0; rk < k; ++rk) {
@@ -268,7 +267,7 @@ __global__ __launch_bounds__(256) void beam_merge_kernel(tst_rows cur, const flo
         int best = -1;
         for (int c = 0; c < nc; ++c)
             if (!((taken >> c) & 1ull) && (best < 0 || cv[c] > cv[best])) best = c;
-        const int64_t dst = base + o;
+        const int64_t dst = obase + o;
         if (best < 0) {  // fewer offers than beams: pad with an ended, worthless hypothesis
             parent[dst] = (int32_t)base; tok[dst] = eos; score[dst] = -INFINITY; fin[dst] = 1; nemit[dst] = 0;
             continue;
@@ -447,14 +446,15 @@ extern "C" int tst_greedy_select(const int32_t* argmax_tok, int64_t n_rows, int3
 }
 
 extern "C" int tst_beam_merge(const tst_rows* cur, const float* top_val, const int32_t* top_idx, const float* lse,
-                              int64_t n_sent, int64_t k, int64_t step, int32_t eos, int32_t* sel_parent, int32_t* sel_tok,
+                              int64_t n_sent, int64_t k, int64_t k_in, int32_t eos, int32_t* sel_parent, int32_t* sel_tok,
                               float* sel_score, int32_t* sel_fin, int32_t* sel_nemit, void* stream) {
     TST_REQUIRE(rows_ok(cur, false) && top_val && top_idx && lse && sel_parent && sel_tok && sel_score && sel_fin &&
                     sel_nemit, TST_ERR_ARG, "tst_beam_merge: null pointer");
-    TST_REQUIRE(n_sent >= 0 && k >= 1 && k <= 8 && step >= 0, TST_ERR_ARG, "tst_beam_merge: need 1 <= k <= 8");
+    TST_REQUIRE(n_sent >= 0 && k >= 1 && k <= 8 && k_in >= 1 && k_in <= k, TST_ERR_ARG,
+                "tst_beam_merge: need 1 <= k_in <= k <= 8");
     if (n_sent == 0) return TST_OK;
     hipLaunchKernelGGL(beam_merge_kernel, dim3(blocks_for(n_sent, 256)), dim3(256), 0, (hipStream_t)stream, *cur, top_val,
-                       top_idx, lse, n_sent, (int)k, (int)step, eos, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit);
+                       top_idx, lse, n_sent, (int)k, (int)k_in, eos, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit);
     return tst_after_launch("tst_beam_merge");
 }
 

@@ -11,6 +11,8 @@ A *session* provides:
   ``needs_anc``       whether it reads the ancestor table (incremental KV cache)
   ``step(rows, n_rows, t) -> logits``   fp32 GPU tensor [>= n_rows, >= V], unit inner stride
   ``reorder(row_parent, n_rows, identity)``  called after each step with the old row of every new row
+Rows: step 0 has one row per sentence (row a = sentence a, per-sentence state in rows 0..B-1 of buffers sized
+for B * beam rows); the first ``reorder`` fans every sentence out to ``beam`` consecutive rows.
 """
 import torch
 
@@ -41,12 +43,11 @@ class DecodeLoop:
         self.cur = K.RowState(R, max_len, dev, session.needs_anc, pad)
         self.nxt = K.RowState(R, max_len, dev, session.needs_anc, pad)
         self.sel = K.Selection(R, dev)
+        # Step 0 runs ONE row per sentence (all beams of a sentence would be identical): row a = sentence a.
+        # The first merge fans each sentence out to its `beam` row slots.
         self.cur.hist[:, 0] = self.bos
         self.cur.tok.fill_(self.bos)
-        self.cur.sent.copy_(torch.arange(n_sent, dtype=torch.int32, device=dev).repeat_interleave(beam))
-        if beam > 1:
-            self.cur.score.fill_(float('-inf'))
-            self.cur.score[::beam] = 0.0
+        self.cur.sent[:n_sent] = torch.arange(n_sent, dtype=torch.int32, device=dev)
         self.lp = length_penalty_table(max_len, alpha).to(dev)
         i32 = dict(dtype=torch.int32, device=dev)
         self.out_tok = torch.full((n_sent, max_len + 1), pad, **i32)
@@ -71,7 +72,8 @@ class DecodeLoop:
         n_sent = self.B
         self.kept = []
         for t in range(T):
-            R = n_sent * k
+            k_in = 1 if t == 0 else k      # rows per sentence going into this step
+            R = n_sent * k_in
             logits = s.step(self.cur, R, t)
             if t < keep_logits:
                 self.kept.append((logits[:R, :s.V].clone(), self.cur.sent[:R].clone(), self.cur.fin[:R].clone()))
@@ -83,7 +85,7 @@ class DecodeLoop:
                 K.greedy_select(self.am, R, self.eos, self.sel, self.cur)
             else:
                 K.logsoftmax_topk(logits, R, s.V, k, self.top_val, self.top_idx, self.lse)
-                K.beam_merge(self.cur, self.top_val, self.top_idx, self.lse, n_sent, k, t, self.eos, self.sel)
+                K.beam_merge(self.cur, self.top_val, self.top_idx, self.lse, n_sent, k, k_in, self.eos, self.sel)
             K.retire_compact(self.cur, self.nxt, self.sel, self.lp, n_sent, k, t, T, self.eos, t == T - 1, self.top_ends,
                              self.out_tok, self.out_len, self.out_score, self.scratch, self.row_parent, self.n_alive)
             self.cur, self.nxt = self.nxt, self.cur

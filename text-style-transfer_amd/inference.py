@@ -29,8 +29,7 @@ class ForeignSession:
         if inputs_batch_dim not in (0, 1, 2):
             raise NotImplementedError  # as /root/reference/src/inference.py:117
         self.model, self.kwargs, self.sub, self.dim = model, kwargs, substitute_inputs, inputs_batch_dim
-        self.inputs = inputs if beam == 1 else inputs.repeat_interleave(beam, dim=inputs_batch_dim)
-        self.enc_mask = enc_mask if (enc_mask is None or beam == 1) else enc_mask.repeat_interleave(beam, dim=0)
+        self.inputs, self.enc_mask = inputs, enc_mask   # one row per sentence until the first reorder fans out
         self.V = vocab_size
 
     def step(self, rows, n, t):
@@ -108,7 +107,7 @@ class InferenceState:
         return ForeignSession(self.model, self.inputs, self.enc_mask, kwargs, self.substitute_inputs,
                               self.inputs_batch_dim, self.beam_size, len(self.vocab))
 
-    def inference(self, keep_logits=0):
+    def _run(self, keep_logits=0):
         if self.sample_type not in ('max', 'sample'):
             raise NotImplementedError  # as /root/reference/src/inference.py:149
         sample = None
@@ -127,13 +126,24 @@ class InferenceState:
         with torch.cuda.device(device):
             loop = DecodeLoop(self._session(), self.batch_size, self.beam_size, self.max_len, self.bos_idx,
                               self.eos_idx, self.pad_idx, self.length_penalty, device, sample)
-            out_tok, out_len, out_score = loop.run(keep_logits)
-            self.loop = loop
-            self.num_steps_done = loop.steps_done
-            lens = out_len.cpu().tolist()
-            toks = out_tok.long()
-            self.scores = out_score
-            self.finished = [toks[i, :n] for i, n in enumerate(lens)]
+            loop.run(keep_logits)
+        self.loop = loop
+        self.num_steps_done = loop.steps_done
+        self.scores = loop.out_score
+        return loop
+
+    def decode_packed(self):
+        """Runs the loop and returns the outputs as device tensors, without building the reference's list of
+        per-sentence tensors: (tokens [B, 1 + max_len] int32, padded with ``<pad>``; lengths [B] int32, BOS
+        included and EOS stripped; scores [B] fp32)."""
+        loop = self._run()
+        return loop.out_tok, loop.out_len, loop.out_score
+
+    def inference(self, keep_logits=0):
+        loop = self._run(keep_logits)
+        lens = loop.out_len.cpu().tolist()
+        toks = loop.out_tok.long()
+        self.finished = [toks[i, :n] for i, n in enumerate(lens)]
         if self.should_stack_finished:
             self.stack_finished()
         return self.finished

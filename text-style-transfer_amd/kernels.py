@@ -142,9 +142,9 @@ def greedy_select(argmax_tok, n_rows, eos, sel, cur):
     call('tst_greedy_select', _p(argmax_tok), n_rows, eos, *sel.ptrs(), st, _stream())
 
 
-def beam_merge(cur, top_val, top_idx, lse, n_sent, k, step, eos, sel):
+def beam_merge(cur, top_val, top_idx, lse, n_sent, k, k_in, eos, sel):
     st = cur.struct()
-    call('tst_beam_merge', st, _p(top_val), _p(top_idx), _p(lse), n_sent, k, step, eos, *sel.ptrs(), _stream())
+    call('tst_beam_merge', st, _p(top_val), _p(top_idx), _p(lse), n_sent, k, k_in, eos, *sel.ptrs(), _stream())
 
 
 def retire_compact(cur, nxt, sel, lp, n_sent, k, step, T, eos, last_step, top_ends, out_tok, out_len, out_score, scratch,

@@ -95,8 +95,10 @@ class GRUSession:
         B = z.shape[1]
         R = B * k
         self.R = R
-        self.h = [z[l].repeat_interleave(k, dim=0).contiguous() for l in range(model.n_layers)]
         f32 = dict(dtype=torch.float32, device=dev)
+        self.h = [torch.empty((R, model.H), **f32) for _ in range(model.n_layers)]
+        for l in range(model.n_layers):
+            self.h[l][:B] = z[l]        # step 0: one row per sentence; the first reorder fans out to k rows
         self.h_alt = [torch.empty((R, model.H), **f32) for _ in range(model.n_layers)]
         self.x = torch.empty((R, model.E), **f32)
         self.gi = torch.empty((R, 3 * model.H), **f32)
