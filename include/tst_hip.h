@@ -8,9 +8,12 @@
  * no allocation, no synchronisation and no global mutable state inside (one thread per stream is
  * safe); sizes are int64_t; the last argument is the hipStream_t to launch on (passed as void*);
  * return value 0 = launched, negative = error (see TST_ERR_*), never an exception.
- * All floating point is fp32 with a fixed operation order ("canonical arithmetic"): a GEMM output is
- * acc = bias[n]; for k ascending: acc = fma(a[m][k], w[k][n], acc); row reductions use interleaved
+ * The _f32 entry points compute in fp32 with a fixed operation order ("canonical arithmetic"): a GEMM output
+ * is acc = bias[n]; for k ascending: acc = fma(a[m][k], w[k][n], acc); row reductions use interleaved
  * partial sums combined by an xor-butterfly; exp/log/sigmoid/tanh are fixed polynomials.
+ * The _bf16 entry points take bf16 storage (passed as void*: 2-byte elements, the upper half of the fp32
+ * bit pattern, rounded to nearest even) and do their arithmetic in fp32: sums of bf16 products on the
+ * matrix cores (v_mfma_f32_32x32x16_bf16) accumulate in fp32; results are rounded to bf16 once, on store.
  */
 #ifndef TST_HIP_H
 #define TST_HIP_H
@@ -48,6 +51,24 @@ int tst_layernorm_f32(const float* x, const float* gamma, const float* beta, flo
 int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res,
                       int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream);
 
+/* y = LayerNorm(x) as above with the result rounded to bf16 (the operand of a following bf16 GEMM). */
+int tst_layernorm_f32_bf16(const float* x, const float* gamma, const float* beta, float eps, void* y, int64_t R, int64_t d,
+                           void* stream);
+
+/* x[r][:] += z[idx[r]][:], rows of d floats (d % 4 == 0): adds the conditioning vector z of a row's sentence
+ * to its embedding (the z argument of the reference's language models, lm(z, x),
+ * /root/reference/src/trainers/lm_trainer.py:72-74). */
+int tst_add_rows_f32(float* x, const float* z, const int32_t* idx, int64_t R, int64_t d, void* stream);
+
+/* C[M][N] = epilogue(bias[n] + sum_k A[m][k] * W[n][k]) on the bf16 matrix cores, fp32 accumulation.
+ * A [M][lda] and W [N][ldw] are bf16 with k contiguous (W is the nn.Linear weight as stored, [out][in]).
+ * epilogue = relu if act == 1, then + res[m][n] (fp32, may alias an fp32 C) if res != NULL; C is bf16 if
+ * out_bf16 != 0, else fp32.  Requirements: K, lda, ldw multiples of 8; ldc a multiple of 8 (bf16) or 4
+ * (fp32); ldr a multiple of 4; 16-byte aligned A, W, C, res. */
+int tst_gemm_mfma_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* res,
+                       int64_t ldr, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, int out_bf16,
+                       void* stream);
+
 /* One decoder self-attention step with an incremental KV cache.
  * cache: [n_pos][slab_rows][3*d] fp32, the fused q|k|v projection output of every past step; the rows of
  * position `pos` (the current step) must already be written.  Row r attends to positions p = 0..pos,
@@ -61,6 +82,13 @@ int tst_attn_self_step_f32(const float* cache, int64_t slab_rows, const int32_t*
  * mask [n_sent][S] bytes (0 = padding, may be NULL); row r uses sentence sent[r]. */
 int tst_attn_cross_step_f32(const float* q, const float* kv, const uint8_t* mask, const int32_t* sent, int64_t S,
                             float* out, int64_t R, int64_t d, int64_t heads, void* stream);
+
+/* The two attention steps with bf16 cache / q / k|v / output (same layouts, 2-byte elements); scores,
+ * softmax and the value sum are computed in fp32 in the same order as the fp32 kernels. */
+int tst_attn_self_step_bf16(const void* cache, int64_t slab_rows, const int32_t* anc, int64_t anc_ld, int64_t pos,
+                            void* out, int64_t R, int64_t d, int64_t heads, void* stream);
+int tst_attn_cross_step_bf16(const void* q, const void* kv, const uint8_t* mask, const int32_t* sent, int64_t S,
+                             void* out, int64_t R, int64_t d, int64_t heads, void* stream);
 
 /* GRU cell update (PyTorch gate order r, z, n); gi = x W_ih^T + b_ih and gh = h W_hh^T + b_hh are [R][3H]:
  * r = sigmoid(gi_r + gh_r), z = sigmoid(gi_z + gh_z), n = tanh(gi_n + r * gh_n), h' = (1 - z) * n + z * h.
@@ -86,6 +114,13 @@ int tst_sample_rows_f32(const float* logits, int64_t ld, int64_t R, int64_t V, f
  * 1 <= k <= 8, k <= V.  Feeds tst_beam_merge (the reference has no beam search; build-defined). */
 int tst_logsoftmax_topk_f32(const float* logits, int64_t ld, int64_t R, int64_t V, int64_t k, float* top_val,
                             int32_t* top_idx, float* lse, void* stream);
+
+/* The three selection kernels on bf16 logits (ld in elements; rows 16-byte aligned when ld % 8 == 0). */
+int tst_argmax_rows_bf16(const void* logits, int64_t ld, int64_t R, int64_t V, int32_t* tok, void* stream);
+int tst_sample_rows_bf16(const void* logits, int64_t ld, int64_t R, int64_t V, float temperature, uint32_t seed,
+                         uint32_t step, const int32_t* sent, int32_t* tok, void* stream);
+int tst_logsoftmax_topk_bf16(const void* logits, int64_t ld, int64_t R, int64_t V, int64_t k, float* top_val,
+                             int32_t* top_idx, float* lse, void* stream);
 
 /* Decode-loop state.  All arrays are device memory owned by the caller; "cur" arrays are read, "nxt"
  * arrays are written (ping-pong).  Rows of one sentence are contiguous (k rows per sentence).

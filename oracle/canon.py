@@ -241,6 +241,84 @@ class _TransformerSession:
         return m.out(layernorm(x, *m.ln))
 
 
+def bf16_round(a):
+    """fp32 array rounded to the nearest bf16 (ties to even), returned as fp32."""
+    u = np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)) << np.uint32(16)
+    return r.astype(np.uint32).view(np.float32)
+
+
+class CanonTransformerLM:
+    """Incremental (KV-cached) evaluation of ``oracle.torch_ref.TransformerLM``.  ``bf16=True`` emulates the
+    bf16 storage points of the GPU's bf16 path on the CPU: weights, LayerNorm outputs, the q|k|v cache,
+    attention outputs, the feed-forward activation and the logits are rounded to bf16; all sums stay fp32.
+    (The matrix cores add the 16 products of one instruction in their own order, so the GPU's bf16 results
+    agree with this emulation up to an occasional bf16 rounding flip, not bit for bit.)"""
+
+    def __init__(self, torch_lm, bf16=False):
+        sd = torch_lm.state_dict()
+        self.bf16 = bf16
+        self.d = sd['embed.weight'].shape[1]
+        self.heads = torch_lm.n_heads
+        self.emb, self.pe = _np(sd['embed.weight']), _np(sd['pe'])
+        self.scale = float(np.float32(math.sqrt(self.d)))
+        self.layers = []
+        i = 0
+        while 'layers.%d.ln1.weight' % i in sd:
+            p = 'layers.%d.' % i
+            L = {n: (_np(sd[p + n + '.weight']), _np(sd[p + n + '.bias'])) for n in ('ln1', 'ln2')}
+            for n in ('q', 'k', 'v', 'o'):
+                L[n] = self._lin(sd, p + 'self_attn.' + n)
+            L['w1'], L['w2'] = self._lin(sd, p + 'ff.w1'), self._lin(sd, p + 'ff.w2')
+            self.layers.append(L)
+            i += 1
+        self.ln = (_np(sd['ln.weight']), _np(sd['ln.bias']))
+        self.out = self._lin(sd, 'out')
+        self.V = self.out.b.shape[0]
+
+    def _lin(self, sd, prefix):
+        lin = _Lin(sd, prefix)
+        if self.bf16:
+            lin.wt = bf16_round(lin.wt)
+        return lin
+
+    def rnd(self, a):
+        return bf16_round(a) if self.bf16 else a
+
+    def session(self, z, rows_per_sentence=1, max_len=512):
+        return _LMSession(self, np.asarray(z, np.float32), rows_per_sentence, max_len)
+
+
+class _LMSession:
+    def __init__(self, m, z, k, max_len):
+        self.m = m
+        B, d = z.shape
+        self.z = np.repeat(z, k, axis=0)
+        R = B * k
+        self.sk = [np.zeros((R, max_len, d), np.float32) for _ in m.layers]
+        self.sv = [np.zeros((R, max_len, d), np.float32) for _ in m.layers]
+
+    def reorder(self, idx):
+        idx = np.asarray(idx, dtype=np.int64)
+        self.z = self.z[idx]
+        self.sk = [a[idx] for a in self.sk]
+        self.sv = [a[idx] for a in self.sv]
+
+    def step(self, tok, t):
+        m, rnd = self.m, self.m.rnd
+        x = embed_posadd(tok, m.emb, m.pe[t], m.scale) + self.z
+        for li, L in enumerate(m.layers):
+            h = rnd(layernorm(x, *L['ln1']))
+            q = rnd(L['q'](h))
+            self.sk[li][:, t] = rnd(L['k'](h))
+            self.sv[li][:, t] = rnd(L['v'](h))
+            a = rnd(attention(q, self.sk[li], self.sv[li], None, None, t + 1, m.heads))
+            x = L['o'](a, res=x)
+            h = rnd(layernorm(x, *L['ln2']))
+            x = L['w2'](rnd(L['w1'](h, act=1)), res=x)
+        return rnd(m.out(rnd(layernorm(x, *m.ln))))
+
+
 class CanonTransformerEncoder:
     """Evaluation of ``oracle.torch_ref.TransformerEncoder`` with the canonical arithmetic."""
 

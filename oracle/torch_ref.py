@@ -212,6 +212,61 @@ class Transformer(nn.Module):
         return self.decoder(encs, trg[:, :-1], enc_mask)
 
 
+class LMLayer(nn.Module):
+    def __init__(self, d_model, n_heads, d_ff):
+        super().__init__()
+        self.ln1 = nn.LayerNorm(d_model)
+        self.self_attn = Attention(d_model, n_heads)
+        self.ln2 = nn.LayerNorm(d_model)
+        self.ff = FeedForward(d_model, d_ff)
+
+    def forward(self, x, causal):
+        h = self.ln1(x)
+        x = x + self.self_attn(h, h, causal)
+        return x + self.ff(self.ln2(x))
+
+
+class TransformerLM(nn.Module):
+    """``TransformerLM(hp.transformer, vocab)``, ``lm(z [B, model_size], x [B, T]) -> [B, T, V]`` and
+    ``lm.inference(src, vocab, eos_token, max_len)`` (``/root/reference/src/trainers/lm_trainer.py:54,72-74,86``;
+    ``model_size: 512`` at ``/root/reference/experiments/lm/config.yml:25-26``).  Decoder-only pre-norm
+    layers; the conditioning vector z is added to the input embedding of every position."""
+
+    def __init__(self, hp, vocab):
+        super().__init__()
+        d = hp.get('model_size', hp.get('d_model'))
+        self.d_model = d
+        self.n_heads = hp.get('n_heads', 8)
+        self.embed = nn.Embedding(len(vocab), d)
+        self.layers = nn.ModuleList([LMLayer(d, self.n_heads, hp.get('d_ff', 4 * d)) for _ in range(hp.get('n_layers', 6))])
+        self.ln = nn.LayerNorm(d)
+        self.out = nn.Linear(d, len(vocab))
+        self.register_buffer('pe', sinusoid_table(hp.get('pe_max_len', 512), d))
+
+    def forward(self, z, x):
+        t = x.shape[1]
+        causal = torch.ones(t, t, dtype=torch.bool, device=x.device).tril().view(1, 1, t, t)
+        h = self.embed(x) * math.sqrt(self.d_model) + self.pe[:t] + z.unsqueeze(1)
+        for layer in self.layers:
+            h = layer(h, causal)
+        return self.out(self.ln(h))
+
+    def inference(self, src, vocab, eos_token='<eos>', max_len=100):
+        """Greedy continuation of the 1-D prefix ``src`` with z = 0; returns the generated ids (no prefix, no EOS)."""
+        eos = vocab.stoi[eos_token]
+        seq = src.reshape(1, -1).long()
+        z = torch.zeros(1, self.d_model)
+        out = []
+        with torch.no_grad():
+            for _ in range(max_len):
+                tok = int(self.forward(z, seq)[0, -1].max(dim=-1)[1])
+                if tok == eos:
+                    break
+                out.append(tok)
+                seq = torch.cat([seq, torch.tensor([[tok]])], dim=1)
+        return torch.tensor(out, dtype=torch.long)
+
+
 # --------------------------------------------------------------------------------------------
 # GRU models
 # --------------------------------------------------------------------------------------------

@@ -182,6 +182,22 @@ def stateful_case(InferenceState, name, H, V, n_layers, B, max_len, eos_bias, ou
     save(name, config, {'z': z.numpy()}, seqs, rec, finished_lens_of(seqs, max_len))
 
 
+def tlm_case(InferenceState, name, hp, V, B, max_len, eos_bias, out_scale, seed, keep=6):
+    """Transformer language model conditioned on z (``lm(z, x)``, /root/reference/src/trainers/lm_trainer.py:72-74)
+    driven by the reference loop in its default (whole-prefix) mode."""
+    rs = np.random.RandomState(seed)
+    vocab = R.synthetic_vocab(V)
+    model = R.synthetic_init(R.TransformerLM(R.HP(hp), vocab), vocab.stoi['<eos>'], eos_bias, out_scale, seed=42)
+    z = torch.from_numpy(rs.standard_normal((B, hp['model_size'])).astype(np.float32))
+    rec = Recorder(model, keep)
+    with torch.no_grad():
+        seqs = InferenceState({'model': rec, 'inputs': z, 'vocab': vocab, 'max_len': max_len}).inference()
+    seqs = [s.tolist() for s in seqs]
+    config = dict(kind='tlm', V=V, hp=dict(hp), weight_seed=42, eos_bias=eos_bias, out_scale=out_scale, max_len=max_len,
+                  data_seed=seed, source='reference src/inference.py')
+    save(name, config, {'z': z.numpy()}, seqs, rec, finished_lens_of(seqs, max_len))
+
+
 def postprocess_case():
     """Outputs of the reference's own ``itos_many`` and ``compute_bleu_for_sents`` on synthetic sentences."""
     from src.utils.data_utils import itos_many
@@ -231,6 +247,8 @@ def main():
              eos_bias=1.0, out_scale=2.0, seed=103)
     gru_case(simple_inference, InferenceState, 'gru_h1024', E=1024, H=1024, V=128, B=4, max_len=24, eos_token='|',
              eos_bias=0.5, out_scale=2.0, seed=104)
+    tlm_case(InferenceState, 'tlm_d64', dict(model_size=64, n_layers=2, n_heads=4, d_ff=128, pe_max_len=32), V=300, B=6,
+             max_len=14, eos_bias=4.0, out_scale=2.0, seed=106)
     stateful_case(InferenceState, 'rnnlm_stateful', H=64, V=50, n_layers=2, B=4, max_len=14, eos_bias=1.0,
                   out_scale=2.0, seed=105)
 

@@ -29,6 +29,11 @@ def torch_model_for(cfg):
         model = R.synthetic_init(R.Transformer(R.HP(cfg['hp']), vocab, vocab), vocab.stoi['<eos>'], cfg['eos_bias'],
                                  cfg['out_scale'], seed=cfg['weight_seed'])
         return model, vocab
+    if kind == 'tlm':
+        vocab = R.synthetic_vocab(cfg['V'])
+        model = R.synthetic_init(R.TransformerLM(R.HP(cfg['hp']), vocab), vocab.stoi['<eos>'], cfg['eos_bias'],
+                                 cfg['out_scale'], seed=cfg['weight_seed'])
+        return model, vocab
     vocab = R.synthetic_vocab(cfg['V'], extra=('|',))
     if kind == 'gru':
         model = R.RNNDecoder(cfg['E'], cfg['H'], vocab)

@@ -10,7 +10,7 @@ from helpers import load_fixture, logits_close, torch_model_for
 from oracle import canon as C
 from oracle import torch_ref as R
 
-GREEDY = ['tfm_v64', 'tfm_v1000', 'gru_h32', 'gru_h1024', 'rnnlm_stateful']
+GREEDY = ['tfm_v64', 'tfm_v1000', 'gru_h32', 'gru_h1024', 'rnnlm_stateful', 'tlm_d64']
 KEEP = 6
 
 
@@ -22,6 +22,8 @@ def run_torch_restatement(fx, model, vocab):
     elif cfg['kind'] == 'gru':
         st = R.RefInferenceState({'model': model, 'inputs': torch.from_numpy(fx['z']), 'vocab': vocab,
                                   'max_len': cfg['max_len'], 'eos_token': cfg['eos_token']})
+    elif cfg['kind'] == 'tlm':
+        st = R.RefInferenceState({'model': model, 'inputs': torch.from_numpy(fx['z']), 'vocab': vocab, 'max_len': cfg['max_len']})
     else:
         st = R.RefInferenceState({'model': model, 'inputs': torch.from_numpy(fx['z']), 'vocab': vocab,
                                   'max_len': cfg['max_len'], 'bos_token': '|', 'eos_token': '|', 'substitute_inputs': True,
@@ -35,6 +37,9 @@ def run_canon(fx, model, vocab):
     if cfg['kind'] == 'transformer':
         sess = C.CanonTransformerDecoder(model.decoder, cfg['hp']['n_heads']).session(fx['encs'], fx['enc_mask'], 1, cfg['max_len'])
         return C.greedy_decode(sess, fx['encs'].shape[0], cfg['max_len'], vocab.stoi['<bos>'], vocab.stoi['<eos>'], KEEP)
+    if cfg['kind'] == 'tlm':
+        sess = C.CanonTransformerLM(model).session(fx['z'], 1, cfg['max_len'])
+        return C.greedy_decode(sess, fx['z'].shape[0], cfg['max_len'], vocab.stoi['<bos>'], vocab.stoi['<eos>'], KEEP)
     sess = C.CanonGRUDecoder(model).session(fx['z'])
     if cfg['kind'] == 'gru':
         return C.greedy_decode(sess, fx['z'].shape[0], cfg['max_len'], vocab.stoi['<bos>'], vocab.stoi[cfg['eos_token']], KEEP)

@@ -11,8 +11,9 @@ from .inference import InferenceState, simple_inference
 from .transformer import HP, Transformer, TransformerDecoder
 from .encoder import TransformerEncoder
 from .rnn import RNNDecoder, RNNLM
+from .lm import TransformerLM
 from .postprocess import itos_many, compute_bleu_for_sents, corpus_bleu
 
 __all__ = ['InferenceState', 'simple_inference', 'Vocab', 'HP', 'Transformer', 'TransformerDecoder',
-           'TransformerEncoder', 'RNNDecoder', 'RNNLM', 'itos_many', 'compute_bleu_for_sents', 'corpus_bleu', 'TstError',
+           'TransformerEncoder', 'RNNDecoder', 'RNNLM', 'TransformerLM', 'itos_many', 'compute_bleu_for_sents', 'corpus_bleu', 'TstError',
            'version']

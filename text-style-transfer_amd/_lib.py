@@ -35,6 +35,15 @@ _PROTOS = {
     'tst_argmax_rows_f32': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_vp], c_int),
     'tst_sample_rows_f32': ([c_vp, c_i64, c_i64, c_i64, c_f32, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp, c_vp], c_int),
     'tst_logsoftmax_topk_f32': ([c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp], c_int),
+    'tst_layernorm_f32_bf16': ([c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_vp], c_int),
+    'tst_add_rows_f32': ([c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
+    'tst_gemm_mfma_bf16': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp],
+                           c_int),
+    'tst_attn_self_step_bf16': ([c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
+    'tst_attn_cross_step_bf16': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
+    'tst_argmax_rows_bf16': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_vp], c_int),
+    'tst_sample_rows_bf16': ([c_vp, c_i64, c_i64, c_i64, c_f32, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp, c_vp], c_int),
+    'tst_logsoftmax_topk_bf16': ([c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp], c_int),
     'tst_beam_merge': ([ctypes.POINTER(TstRows), c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                         c_vp], c_int),
     'tst_greedy_select': ([c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(TstRows), c_vp], c_int),

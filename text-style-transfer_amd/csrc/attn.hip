@@ -13,11 +13,28 @@ namespace {
 
 constexpr int MAXP = 256;  // positions per row supported by the one-score-per-lane softmax
 
-template <bool SELF, int NCH, int VEC>
+// 4 consecutive elements as floats (fp32: one 16-byte load; bf16: one 8-byte load, widened exactly)
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 ld4(const __bf16* p) {
+    const uint2 u = *reinterpret_cast<const uint2*>(p);
+    return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                       __uint_as_float(u.y & 0xffff0000u));
+}
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ float2 ld2(const __bf16* p) {
+    const uint32_t u = *reinterpret_cast<const uint32_t*>(p);
+    return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
+}
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const __bf16* p) { return (float)*p; }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(__bf16* p, float v) { *p = (__bf16)v; }
+
+template <typename T, bool SELF, int NCH, int VEC>
 __global__ __launch_bounds__(256) void attn_step_kernel(
     // SELF: cache [n_pos][slab_rows][3d], anc; else q [R][d], kv [n_sent][S][2d], mask, sent
-    const float* __restrict__ base, int64_t slab_stride, const int32_t* __restrict__ anc, int64_t anc_ld,
-    const float* __restrict__ qbuf, const uint8_t* __restrict__ mask, const int32_t* __restrict__ sent, int n, float* __restrict__ out,
+    const T* __restrict__ base, int64_t slab_stride, const int32_t* __restrict__ anc, int64_t anc_ld,
+    const T* __restrict__ qbuf, const uint8_t* __restrict__ mask, const int32_t* __restrict__ sent, int n, T* __restrict__ out,
     int64_t R, int d, int heads, int dh, float scale) {
     __shared__ float sc[4][MAXP];
     __shared__ int slot[4][MAXP];
@@ -29,7 +46,7 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
     const int h = (int)(gw - r * heads);
     const int pos = n - 1;
 
-    const float* qp;
+    const T* qp;
     int64_t ent = 0;
     if (SELF) {
         for (int p = lane; p < n; p += 64) slot[w][p] = (p < pos) ? anc[r * anc_ld + p] : (int)r;
@@ -43,15 +60,15 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
 #pragma unroll
     for (int c = 0; c < NCH; ++c) {
         const int ch = j + 16 * c;
-        qv[c] = (ch * 4 < dh) ? reinterpret_cast<const float4*>(qp)[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+        qv[c] = (ch * 4 < dh) ? ld4(qp + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();
 
-    auto krow = [&](int p) -> const float* {
+    auto krow = [&](int p) -> const T* {
         if (SELF) return base + (int64_t)p * slab_stride + (int64_t)slot[w][p] * 3 * d + d + h * dh;
         return base + (ent * n + p) * 2 * (int64_t)d + h * dh;
     };
-    auto vrow = [&](int p) -> const float* { return krow(p) + d; };
+    auto vrow = [&](int p) -> const T* { return krow(p) + d; };
 
     // scores
     for (int p0 = 0; p0 < n; p0 += 4) {
@@ -60,12 +77,12 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
         bool live = p < n;
         if (!SELF && live && mask != nullptr && mask[ent * n + p] == 0) live = false;
         if (live) {
-            const float4* kp = reinterpret_cast<const float4*>(krow(p));
+            const T* kp = krow(p);
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int ch = j + 16 * c;
                 if (ch * 4 < dh) {
-                    const float4 kv = kp[ch];
+                    const float4 kv = ld4(kp + 4 * ch);
                     part = __builtin_fmaf(qv[c].x, kv.x, part);
                     part = __builtin_fmaf(qv[c].y, kv.y, part);
                     part = __builtin_fmaf(qv[c].z, kv.z, part);
@@ -105,7 +122,7 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
     __syncthreads();
 
     // weighted value sum, positions ascending
-    float* orow = out + r * d + h * dh;
+    T* orow = out + r * d + h * dh;
     for (int c0 = lane * VEC; c0 < dh; c0 += 64 * VEC) {
         float acc[VEC];
 #pragma unroll
@@ -114,29 +131,29 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
         for (int p = 0; p < n; ++p) {
             const float wp = sc[w][p];
             if (wp == 0.0f) continue;  // padding (or underflow): fma(0, v, acc) == acc; wave-uniform branch
-            const float* vp = vrow(p) + c0;
+            const T* vp = vrow(p) + c0;
             if (VEC == 4) {
-                const float4 v = *reinterpret_cast<const float4*>(vp);
+                const float4 v = ld4(vp);
                 acc[0] = __builtin_fmaf(wp, v.x, acc[0]);
                 acc[1 % VEC] = __builtin_fmaf(wp, v.y, acc[1 % VEC]);
                 acc[2 % VEC] = __builtin_fmaf(wp, v.z, acc[2 % VEC]);
                 acc[3 % VEC] = __builtin_fmaf(wp, v.w, acc[3 % VEC]);
             } else if (VEC == 2) {
-                const float2 v = *reinterpret_cast<const float2*>(vp);
+                const float2 v = ld2(vp);
                 acc[0] = __builtin_fmaf(wp, v.x, acc[0]);
                 acc[1 % VEC] = __builtin_fmaf(wp, v.y, acc[1 % VEC]);
             } else {
-                acc[0] = __builtin_fmaf(wp, vp[0], acc[0]);
+                acc[0] = __builtin_fmaf(wp, ld1(vp), acc[0]);
             }
         }
 #pragma unroll
-        for (int e = 0; e < VEC; ++e) orow[c0 + e] = acc[e];
+        for (int e = 0; e < VEC; ++e) st1(orow + c0 + e, acc[e]);
     }
 }
 
-template <bool SELF>
-int launch_attn(const float* base, int64_t slab_stride, const int32_t* anc, int64_t anc_ld, const float* q,
-                const uint8_t* mask, const int32_t* sent, int64_t n, float* out, int64_t R, int64_t d, int64_t heads,
+template <typename T, bool SELF>
+int launch_attn(const T* base, int64_t slab_stride, const int32_t* anc, int64_t anc_ld, const T* q,
+                const uint8_t* mask, const int32_t* sent, int64_t n, T* out, int64_t R, int64_t d, int64_t heads,
                 hipStream_t stream, const char* name) {
     const int64_t dh = d / heads;
     const float scale = (float)(1.0 / sqrt((double)dh));  // rounded once, from the double-precision value
@@ -144,7 +161,7 @@ int launch_attn(const float* base, int64_t slab_stride, const int32_t* anc, int6
     const int nch = (int)((dh + 63) / 64);
     const int vec = (dh % 256 == 0) ? 4 : (dh % 128 == 0) ? 2 : 1;
 #define TST_ATTN_CASE(NCH_, VEC_)                                                                                        \
-    hipLaunchKernelGGL((attn_step_kernel<SELF, NCH_, VEC_>), dim3(grid), dim3(256), 0, stream, base, slab_stride, anc,  \
+    hipLaunchKernelGGL((attn_step_kernel<T, SELF, NCH_, VEC_>), dim3(grid), dim3(256), 0, stream, base, slab_stride, anc,  \
                        anc_ld, q, mask, sent, (int)n, out, R, (int)d, (int)heads, (int)dh, scale)
     if (nch == 1 && vec == 1) TST_ATTN_CASE(1, 1);
     else if (nch == 2 && vec == 2) TST_ATTN_CASE(2, 2);
@@ -170,7 +187,7 @@ extern "C" int tst_attn_self_step_f32(const float* cache, int64_t slab_rows, con
     TST_REQUIRE(pos + 1 <= MAXP && pos <= anc_ld, TST_ERR_UNSUPPORTED, "tst_attn_self_step_f32: at most %d positions", MAXP);
     TST_REQUIRE(tst_aligned16(cache) && tst_aligned16(out), TST_ERR_ARG, "tst_attn_self_step_f32: alignment");
     if (R == 0) return TST_OK;
-    return launch_attn<true>(cache, slab_rows * 3 * d, anc, anc_ld, nullptr, nullptr, nullptr, pos + 1, out, R, d, heads,
+    return launch_attn<float, true>(cache, slab_rows * 3 * d, anc, anc_ld, nullptr, nullptr, nullptr, pos + 1, out, R, d, heads,
                              (hipStream_t)stream, "tst_attn_self_step_f32");
 }
 
@@ -182,6 +199,31 @@ extern "C" int tst_attn_cross_step_f32(const float* q, const float* kv, const ui
     TST_REQUIRE(S <= MAXP, TST_ERR_UNSUPPORTED, "tst_attn_cross_step_f32: at most %d source positions", MAXP);
     TST_REQUIRE(tst_aligned16(q) && tst_aligned16(kv) && tst_aligned16(out), TST_ERR_ARG, "tst_attn_cross_step_f32: alignment");
     if (R == 0) return TST_OK;
-    return launch_attn<false>(kv, 0, nullptr, 0, q, mask, sent, S, out, R, d, heads, (hipStream_t)stream,
+    return launch_attn<float, false>(kv, 0, nullptr, 0, q, mask, sent, S, out, R, d, heads, (hipStream_t)stream,
                               "tst_attn_cross_step_f32");
+}
+
+// bf16 storage (cache, q, k|v and output), fp32 arithmetic in the same order as the fp32 kernels
+extern "C" int tst_attn_self_step_bf16(const void* cache, int64_t slab_rows, const int32_t* anc, int64_t anc_ld,
+                                       int64_t pos, void* out, int64_t R, int64_t d, int64_t heads, void* stream) {
+    TST_REQUIRE(cache && out && (anc || pos == 0), TST_ERR_ARG, "tst_attn_self_step_bf16: null pointer");
+    TST_REQUIRE(R >= 0 && R <= slab_rows && d > 0 && heads > 0 && d % heads == 0 && (d / heads) % 4 == 0 && pos >= 0,
+                TST_ERR_ARG, "tst_attn_self_step_bf16: bad sizes");
+    TST_REQUIRE(pos + 1 <= MAXP && pos <= anc_ld, TST_ERR_UNSUPPORTED, "tst_attn_self_step_bf16: at most %d positions", MAXP);
+    TST_REQUIRE(tst_aligned16(cache) && tst_aligned16(out), TST_ERR_ARG, "tst_attn_self_step_bf16: alignment");
+    if (R == 0) return TST_OK;
+    return launch_attn<__bf16, true>((const __bf16*)cache, slab_rows * 3 * d, anc, anc_ld, nullptr, nullptr, nullptr, pos + 1,
+                                     (__bf16*)out, R, d, heads, (hipStream_t)stream, "tst_attn_self_step_bf16");
+}
+
+extern "C" int tst_attn_cross_step_bf16(const void* q, const void* kv, const uint8_t* mask, const int32_t* sent, int64_t S,
+                                        void* out, int64_t R, int64_t d, int64_t heads, void* stream) {
+    TST_REQUIRE(q && kv && sent && out, TST_ERR_ARG, "tst_attn_cross_step_bf16: null pointer");
+    TST_REQUIRE(R >= 0 && d > 0 && heads > 0 && d % heads == 0 && (d / heads) % 4 == 0 && S > 0, TST_ERR_ARG,
+                "tst_attn_cross_step_bf16: bad sizes");
+    TST_REQUIRE(S <= MAXP, TST_ERR_UNSUPPORTED, "tst_attn_cross_step_bf16: at most %d source positions", MAXP);
+    TST_REQUIRE(tst_aligned16(q) && tst_aligned16(kv) && tst_aligned16(out), TST_ERR_ARG, "tst_attn_cross_step_bf16: alignment");
+    if (R == 0) return TST_OK;
+    return launch_attn<__bf16, false>((const __bf16*)kv, 0, nullptr, 0, (const __bf16*)q, mask, sent, S, (__bf16*)out, R, d,
+                                      heads, (hipStream_t)stream, "tst_attn_cross_step_bf16");
 }

@@ -24,9 +24,19 @@ __global__ __launch_bounds__(256) void embed_posadd_kernel(const int32_t* __rest
     reinterpret_cast<float4*>(x)[i] = o;
 }
 
-// one wave per row; lane l owns the float4 chunks l, l + 64, ... (element c -> partial (c / 4) % 64)
+__device__ __forceinline__ void store4(float* y, int64_t i4, const float4& o) { reinterpret_cast<float4*>(y)[i4] = o; }
+__device__ __forceinline__ void store4(__bf16* y, int64_t i4, const float4& o) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 v;
+    v[0] = (__bf16)o.x; v[1] = (__bf16)o.y; v[2] = (__bf16)o.z; v[3] = (__bf16)o.w;
+    reinterpret_cast<bf16x4*>(y)[i4] = v;
+}
+
+// one wave per row; lane l owns the float4 chunks l, l + 64, ... (element c -> partial (c / 4) % 64);
+// TO = float, or __bf16 when the result feeds a bf16 GEMM (statistics and affine map stay fp32, one rounding)
+template <typename TO>
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, const float* __restrict__ g,
-                                                        const float* __restrict__ b, float eps, float* __restrict__ y,
+                                                        const float* __restrict__ b, float eps, TO* __restrict__ y,
                                                         int64_t R, int d4) {
     const int lane = threadIdx.x & 63;
     const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -50,7 +60,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
     const float var = wave_sum_butterfly(p) / d;
     const float rstd = 1.0f / sqrtf(var + eps);
-    float4* yr = reinterpret_cast<float4*>(y) + r * d4;
     for (int c = lane; c < d4; c += 64) {
         const float4 v = xr[c];
         const float4 gg = reinterpret_cast<const float4*>(g)[c];
@@ -60,7 +69,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         o.y = __builtin_fmaf((v.y - mean) * rstd, gg.y, bb.y);
         o.z = __builtin_fmaf((v.z - mean) * rstd, gg.z, bb.z);
         o.w = __builtin_fmaf((v.w - mean) * rstd, gg.w, bb.w);
-        yr[c] = o;
+        store4(y, r * d4 + c, o);
     }
 }
 
@@ -89,6 +98,19 @@ __global__ __launch_bounds__(256) void gru_cell_kernel(const float* __restrict__
     o.z = gru_elem(ir.z, iz.z, in.z, hr.z, hz.z, hn.z, hv.z);
     o.w = gru_elem(ir.w, iz.w, in.w, hr.w, hz.w, hn.w, hv.w);
     reinterpret_cast<float4*>(h_out)[i] = o;
+}
+
+// x[r][:] += z[idx[r]][:]
+__global__ __launch_bounds__(256) void add_rows_kernel(float* __restrict__ x, const float* __restrict__ z,
+                                                       const int32_t* __restrict__ idx, int64_t R, int d4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * d4) return;
+    const int64_t r = i / d4;
+    const int c4 = (int)(i - r * d4);
+    float4 v = reinterpret_cast<float4*>(x)[i];
+    const float4 a = reinterpret_cast<const float4*>(z)[(int64_t)idx[r] * d4 + c4];
+    v.x = v.x + a.x; v.y = v.y + a.y; v.z = v.z + a.z; v.w = v.w + a.w;
+    reinterpret_cast<float4*>(x)[i] = v;
 }
 
 __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
@@ -123,9 +145,31 @@ extern "C" int tst_layernorm_f32(const float* x, const float* gamma, const float
     TST_REQUIRE(tst_aligned16(x) && tst_aligned16(y) && tst_aligned16(gamma) && tst_aligned16(beta), TST_ERR_ARG,
                 "tst_layernorm_f32: alignment");
     if (R == 0) return TST_OK;
-    hipLaunchKernelGGL(layernorm_kernel, dim3(blocks_for(R, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, y,
-                       R, (int)(d / 4));
+    hipLaunchKernelGGL(layernorm_kernel<float>, dim3(blocks_for(R, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                       eps, y, R, (int)(d / 4));
     return tst_after_launch("tst_layernorm_f32");
+}
+
+extern "C" int tst_layernorm_f32_bf16(const float* x, const float* gamma, const float* beta, float eps, void* y, int64_t R,
+                                      int64_t d, void* stream) {
+    TST_REQUIRE(x && gamma && beta && y, TST_ERR_ARG, "tst_layernorm_f32_bf16: null pointer");
+    TST_REQUIRE(R >= 0 && d > 0 && d % 4 == 0, TST_ERR_ARG, "tst_layernorm_f32_bf16: need d %% 4 == 0");
+    TST_REQUIRE(tst_aligned16(x) && tst_aligned16(y) && tst_aligned16(gamma) && tst_aligned16(beta), TST_ERR_ARG,
+                "tst_layernorm_f32_bf16: alignment");
+    if (R == 0) return TST_OK;
+    hipLaunchKernelGGL(layernorm_kernel<__bf16>, dim3(blocks_for(R, 4)), dim3(256), 0, (hipStream_t)stream, x, gamma, beta,
+                       eps, (__bf16*)y, R, (int)(d / 4));
+    return tst_after_launch("tst_layernorm_f32_bf16");
+}
+
+extern "C" int tst_add_rows_f32(float* x, const float* z, const int32_t* idx, int64_t R, int64_t d, void* stream) {
+    TST_REQUIRE(x && z && idx, TST_ERR_ARG, "tst_add_rows_f32: null pointer");
+    TST_REQUIRE(R >= 0 && d > 0 && d % 4 == 0, TST_ERR_ARG, "tst_add_rows_f32: need d %% 4 == 0");
+    TST_REQUIRE(tst_aligned16(x) && tst_aligned16(z), TST_ERR_ARG, "tst_add_rows_f32: alignment");
+    if (R == 0) return TST_OK;
+    hipLaunchKernelGGL(add_rows_kernel, dim3(blocks_for(R * (d / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, z, idx, R,
+                       (int)(d / 4));
+    return tst_after_launch("tst_add_rows_f32");
 }
 
 extern "C" int tst_gru_cell_step_f32(const float* gi, const float* gh, const float* h, float* h_out, int64_t R, int64_t H,

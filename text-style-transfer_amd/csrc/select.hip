@@ -33,31 +33,52 @@ __device__ __forceinline__ void block_argmax(float& v, int& i, float* red_v, int
         if (better(red_v[q], red_i[q], v, i)) { v = red_v[q]; i = red_i[q]; }
 }
 
-// loads chunk c (elements 4c..4c+3) of a row; elements at or beyond V read as -inf
-__device__ __forceinline__ float4 load_chunk(const float* xr, int c, int V, bool vec_ok) {
-    if (vec_ok && 4 * c + 3 < V) return reinterpret_cast<const float4*>(xr)[c];
-    float4 v;
-    v.x = 4 * c + 0 < V ? xr[4 * c + 0] : -INFINITY;
-    v.y = 4 * c + 1 < V ? xr[4 * c + 1] : -INFINITY;
-    v.z = 4 * c + 2 < V ? xr[4 * c + 2] : -INFINITY;
-    v.w = 4 * c + 3 < V ? xr[4 * c + 3] : -INFINITY;
-    return v;
+// Logits come as fp32 or bf16; a "chunk" is 16 bytes of a row: EPC = 4 fp32 or 8 bf16 elements.  All
+// arithmetic is fp32 on the exactly widened values.
+template <typename T> struct Elem;
+template <> struct Elem<float> { static constexpr int EPC = 4; };
+template <> struct Elem<__bf16> { static constexpr int EPC = 8; };
+
+// loads chunk c of a row as floats; elements at or beyond V read as -inf
+__device__ __forceinline__ void load_chunk(const float* xr, int c, int V, bool vec_ok, float (&o)[4]) {
+    if (vec_ok && 4 * c + 3 < V) {
+        const float4 v = reinterpret_cast<const float4*>(xr)[c];
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = 4 * c + q < V ? xr[4 * c + q] : -INFINITY;
 }
 
-__global__ __launch_bounds__(256) void argmax_rows_kernel(const float* __restrict__ x, int64_t ld, int V,
+__device__ __forceinline__ void load_chunk(const __bf16* xr, int c, int V, bool vec_ok, float (&o)[8]) {
+    if (vec_ok && 8 * c + 7 < V) {
+        const uint4 u = reinterpret_cast<const uint4*>(xr)[c];
+        o[0] = __uint_as_float(u.x << 16); o[1] = __uint_as_float(u.x & 0xffff0000u);
+        o[2] = __uint_as_float(u.y << 16); o[3] = __uint_as_float(u.y & 0xffff0000u);
+        o[4] = __uint_as_float(u.z << 16); o[5] = __uint_as_float(u.z & 0xffff0000u);
+        o[6] = __uint_as_float(u.w << 16); o[7] = __uint_as_float(u.w & 0xffff0000u);
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = 8 * c + q < V ? (float)xr[8 * c + q] : -INFINITY;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void argmax_rows_kernel(const T* __restrict__ x, int64_t ld, int V,
                                                           int32_t* __restrict__ tok, int vec_ok) {
+    constexpr int EPC = Elem<T>::EPC;
     __shared__ float red_v[4];
     __shared__ int red_i[4];
-    const float* xr = x + (int64_t)blockIdx.x * ld;
-    const int nch = (V + 3) >> 2;
+    const T* xr = x + (int64_t)blockIdx.x * ld;
+    const int nch = (V + EPC - 1) / EPC;
     float bv = -INFINITY;
     int bi = INT_MAX;
     for (int c = threadIdx.x; c < nch; c += 256) {
-        const float4 v = load_chunk(xr, c, V, vec_ok != 0);
-        if (v.x > bv) { bv = v.x; bi = 4 * c; }
-        if (v.y > bv) { bv = v.y; bi = 4 * c + 1; }
-        if (v.z > bv) { bv = v.z; bi = 4 * c + 2; }
-        if (v.w > bv) { bv = v.w; bi = 4 * c + 3; }
+        float e[EPC];
+        load_chunk(xr, c, V, vec_ok != 0, e);
+#pragma unroll
+        for (int q = 0; q < EPC; ++q)
+            if (e[q] > bv) { bv = e[q]; bi = EPC * c + q; }
     }
     block_argmax(bv, bi, red_v, red_i);
     if (threadIdx.x == 0) tok[blockIdx.x] = bi == INT_MAX ? 0 : bi;
@@ -70,22 +91,24 @@ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 
 // Gumbel-max sampling: argmax_v (x_v / temperature - log(-log(u_v))), u_v from a counter-based hash of
 // (seed, step, sentence, v); first maximal index wins.  One workgroup per row.
-__global__ __launch_bounds__(256) void sample_rows_kernel(const float* __restrict__ x, int64_t ld, int V, float temperature,
+template <typename T>
+__global__ __launch_bounds__(256) void sample_rows_kernel(const T* __restrict__ x, int64_t ld, int V, float temperature,
                                                           uint32_t seed, uint32_t step, const int32_t* __restrict__ sent,
                                                           int32_t* __restrict__ tok, int vec_ok) {
+    constexpr int EPC = Elem<T>::EPC;
     __shared__ float red_v[4];
     __shared__ int red_i[4];
-    const float* xr = x + (int64_t)blockIdx.x * ld;
+    const T* xr = x + (int64_t)blockIdx.x * ld;
     const uint32_t rowkey = mix32((uint32_t)sent[blockIdx.x] * 0x9E3779B9u + mix32(step * 0x85EBCA6Bu + seed));
-    const int nch = (V + 3) >> 2;
+    const int nch = (V + EPC - 1) / EPC;
     float bv = -INFINITY;
     int bi = INT_MAX;
     for (int c = threadIdx.x; c < nch; c += 256) {
-        const float4 v = load_chunk(xr, c, V, vec_ok != 0);
-        const float e[4] = {v.x, v.y, v.z, v.w};
+        float e[EPC];
+        load_chunk(xr, c, V, vec_ok != 0, e);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int id = 4 * c + q;
+        for (int q = 0; q < EPC; ++q) {
+            const int id = EPC * c + q;
             const uint32_t h = mix32((uint32_t)id ^ rowkey);
             const float u = (float)(h >> 9) * 1.1920928955078125e-07f + 5.9604644775390625e-08f;
             const float key = e[q] / temperature + (-d_log(-d_log(u)));
@@ -98,25 +121,25 @@ __global__ __launch_bounds__(256) void sample_rows_kernel(const float* __restric
 
 constexpr int CAND_CAP = 1024;  // LDS candidate list of the top-k filter
 
-// online log-sum-exp update with a group of 16 values (ascending index order)
-__device__ __forceinline__ void lse_consume(const float4 (&vv)[4], float& m, float& sacc) {
+// online log-sum-exp update with a group of 4 chunks (ascending index order within the group)
+template <int EPC>
+__device__ __forceinline__ void lse_consume(const float (&vv)[4][EPC], float& m, float& sacc) {
     float mn = m;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) mn = fmaxf(fmaxf(fmaxf(mn, vv[u].x), fmaxf(vv[u].y, vv[u].z)), vv[u].w);
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < EPC; ++q) mn = fmaxf(mn, vv[u][q]);
     sacc = sacc * d_exp_le0(m - mn);
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-        sacc = sacc + d_exp_le0(vv[u].x - mn);
-        sacc = sacc + d_exp_le0(vv[u].y - mn);
-        sacc = sacc + d_exp_le0(vv[u].z - mn);
-        sacc = sacc + d_exp_le0(vv[u].w - mn);
-    }
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < EPC; ++q) sacc = sacc + d_exp_le0(vv[u][q] - mn);
     m = mn;
 }
 
 // One workgroup per row, ONE pass over the row: each logit is read from HBM once and only a few registers
-// are live, so occupancy is high and the loads overlap the arithmetic.  Thread t owns the float4 chunks
-// t, t + 256, ... and consumes them four at a time (16 values x_i, ascending index) into an online
+// are live, so occupancy is high and the loads overlap the arithmetic.  Thread t owns the 16-byte chunks
+// t, t + 256, ... and consumes them four at a time (values x_i in ascending index order) into an online
 // log-sum-exp state:  m' = max(m, x_i);  s = s * exp(m - m') + sum_i exp(x_i - m');  m = m'.
 // Then M = max of the 256 m, total = butterfly sum of s * exp(m - M) (wave butterfly, waves left to right),
 // lse = M + log(total).
@@ -125,10 +148,11 @@ __device__ __forceinline__ void lse_consume(const float4 (&vv)[4], float& m, flo
 // is >= tau, so only those (about K) threads re-read their chunks and push elements >= tau to an LDS list,
 // from which K more rounds pick the result (value desc, index asc).  If the list overflows (many equal
 // values) the K rounds run over the whole row instead.
-template <int K, bool VEC>
-__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __restrict__ x, int64_t ld, int V,
+template <typename T, int K, bool VEC>
+__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const T* __restrict__ x, int64_t ld, int V,
                                                               float* __restrict__ top_val, int32_t* __restrict__ top_idx,
                                                               float* __restrict__ lse) {
+    constexpr int EPC = Elem<T>::EPC;
     __shared__ float red_v[4];
     __shared__ int red_i[4];
     __shared__ float red_s[4];
@@ -137,26 +161,26 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __res
     __shared__ int cand_n;
     const int t = threadIdx.x;
     const int64_t r = blockIdx.x;
-    const float* xr = x + r * ld;
-    const int nch = (V + 3) >> 2;
+    const T* xr = x + r * ld;
+    const int nch = (V + EPC - 1) / EPC;
     if (t == 0) cand_n = 0;
     float m = -INFINITY, sacc = 0.0f;
     // a chunk beyond the row reads as -inf and contributes exp(-inf) = 0
     int c0 = t;
     if (VEC) {  // groups that lie fully inside the row: unguarded 16-byte loads
-        const int nfull = V >> 2;
+        const int nfull = V / EPC;
         for (; c0 + 768 < nfull; c0 += 1024) {
-            float4 vv[4];
+            float vv[4][EPC];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) vv[u] = reinterpret_cast<const float4*>(xr)[c0 + 256 * u];
-            lse_consume(vv, m, sacc);
+            for (int u = 0; u < 4; ++u) load_chunk(xr, c0 + 256 * u, INT_MAX, true, vv[u]);
+            lse_consume<EPC>(vv, m, sacc);
         }
     }
     for (; c0 < nch; c0 += 1024) {  // ragged end of the row (and rows that are not 16-byte aligned)
-        float4 vv[4];
+        float vv[4][EPC];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) vv[u] = load_chunk(xr, c0 + 256 * u, V, VEC);
-        lse_consume(vv, m, sacc);
+        for (int u = 0; u < 4; ++u) load_chunk(xr, c0 + 256 * u, V, VEC, vv[u]);
+        lse_consume<EPC>(vv, m, sacc);
     }
     // K-th largest thread maximum (ties between threads: lower thread first)
     float M = -INFINITY, tau = -INFINITY, cand = m;
@@ -172,13 +196,13 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __res
     if ((t & 63) == 0) red_s[t >> 6] = part;
     if (m >= tau) {  // about K threads
         for (int c = t; c < nch; c += 256) {
-            const float4 v = load_chunk(xr, c, V, VEC);
-            const float e[4] = {v.x, v.y, v.z, v.w};
+            float e[EPC];
+            load_chunk(xr, c, V, VEC, e);
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (e[q] >= tau && 4 * c + q < V) {
+            for (int q = 0; q < EPC; ++q)
+                if (e[q] >= tau && EPC * c + q < V) {
                     const int at = atomicAdd(&cand_n, 1);
-                    if (at < CAND_CAP) { cand_v[at] = e[q]; cand_i[at] = 4 * c + q; }
+                    if (at < CAND_CAP) { cand_v[at] = e[q]; cand_i[at] = EPC * c + q; }
                 }
         }
     }
@@ -206,11 +230,11 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const float* __res
             float bv = -INFINITY;
             int bi = INT_MAX;
             for (int c = t; c < nch; c += 256) {
-                const float4 v = load_chunk(xr, c, V, VEC);
-                const float e[4] = {v.x, v.y, v.z, v.w};
+                float e[EPC];
+                load_chunk(xr, c, V, VEC, e);
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const int id = 4 * c + q;
+                for (int q = 0; q < EPC; ++q) {
+                    const int id = EPC * c + q;
                     const bool after = e[q] < lastv || (e[q] == lastv && id > lasti);
                     if (id < V && after && better(e[q], id, bv, bi)) { bv = e[q]; bi = id; }
                 }
@@ -376,15 +400,59 @@ __global__ __launch_bounds__(256) void gather_state_kernel(tst_rows cur, tst_row
 
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
-inline int row_vec_ok(const float* x, int64_t ld) { return (tst_aligned16(x) && ld % 4 == 0) ? 1 : 0; }
+template <typename T>
+inline int row_vec_ok(const T* x, int64_t ld) { return (tst_aligned16(x) && ld % Elem<T>::EPC == 0) ? 1 : 0; }
 
-template <int K>
-int launch_topk(const float* logits, int64_t ld, int64_t R, int64_t V, float* tv, int32_t* ti, float* lse, hipStream_t st) {
+template <typename T, int K>
+int launch_topk(const T* logits, int64_t ld, int64_t R, int64_t V, float* tv, int32_t* ti, float* lse, hipStream_t st,
+                const char* name) {
     if (row_vec_ok(logits, ld))
-        hipLaunchKernelGGL((logsoftmax_topk_kernel<K, true>), dim3((unsigned)R), dim3(256), 0, st, logits, ld, (int)V, tv, ti, lse);
+        hipLaunchKernelGGL((logsoftmax_topk_kernel<T, K, true>), dim3((unsigned)R), dim3(256), 0, st, logits, ld, (int)V, tv, ti, lse);
     else
-        hipLaunchKernelGGL((logsoftmax_topk_kernel<K, false>), dim3((unsigned)R), dim3(256), 0, st, logits, ld, (int)V, tv, ti, lse);
-    return tst_after_launch("tst_logsoftmax_topk_f32");
+        hipLaunchKernelGGL((logsoftmax_topk_kernel<T, K, false>), dim3((unsigned)R), dim3(256), 0, st, logits, ld, (int)V, tv, ti, lse);
+    return tst_after_launch(name);
+}
+
+template <typename T>
+int topk_entry(const T* logits, int64_t ld, int64_t R, int64_t V, int64_t k, float* top_val, int32_t* top_idx, float* lse,
+               void* stream, const char* name) {
+    TST_REQUIRE(logits && top_val && top_idx && lse, TST_ERR_ARG, "%s: null pointer", name);
+    TST_REQUIRE(R >= 0 && V > 0 && ld >= V && V < (1ll << 30) && R < (1ll << 31), TST_ERR_ARG, "%s: bad sizes", name);
+    TST_REQUIRE(k >= 1 && k <= 8 && k <= V, TST_ERR_UNSUPPORTED, "%s: need 1 <= k <= min(8, V)", name);
+    if (R == 0) return TST_OK;
+    hipStream_t st = (hipStream_t)stream;
+    switch (k) {
+        case 1: return launch_topk<T, 1>(logits, ld, R, V, top_val, top_idx, lse, st, name);
+        case 2: return launch_topk<T, 2>(logits, ld, R, V, top_val, top_idx, lse, st, name);
+        case 3: return launch_topk<T, 3>(logits, ld, R, V, top_val, top_idx, lse, st, name);
+        case 4: return launch_topk<T, 4>(logits, ld, R, V, top_val, top_idx, lse, st, name);
+        case 5: return launch_topk<T, 5>(logits, ld, R, V, top_val, top_idx, lse, st, name);
+        case 6: return launch_topk<T, 6>(logits, ld, R, V, top_val, top_idx, lse, st, name);
+        case 7: return launch_topk<T, 7>(logits, ld, R, V, top_val, top_idx, lse, st, name);
+        default: return launch_topk<T, 8>(logits, ld, R, V, top_val, top_idx, lse, st, name);
+    }
+}
+
+template <typename T>
+int argmax_entry(const T* logits, int64_t ld, int64_t R, int64_t V, int32_t* tok, void* stream, const char* name) {
+    TST_REQUIRE(logits && tok, TST_ERR_ARG, "%s: null pointer", name);
+    TST_REQUIRE(R >= 0 && V > 0 && ld >= V && V < (1ll << 30) && R < (1ll << 31), TST_ERR_ARG, "%s: bad sizes", name);
+    if (R == 0) return TST_OK;
+    hipLaunchKernelGGL(argmax_rows_kernel<T>, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, ld, (int)V, tok,
+                       row_vec_ok(logits, ld));
+    return tst_after_launch(name);
+}
+
+template <typename T>
+int sample_entry(const T* logits, int64_t ld, int64_t R, int64_t V, float temperature, uint32_t seed, uint32_t step,
+                 const int32_t* sent, int32_t* tok, void* stream, const char* name) {
+    TST_REQUIRE(logits && sent && tok, TST_ERR_ARG, "%s: null pointer", name);
+    TST_REQUIRE(R >= 0 && V > 0 && ld >= V && V < (1ll << 30) && R < (1ll << 31) && temperature > 0.0f, TST_ERR_ARG,
+                "%s: bad sizes or temperature <= 0", name);
+    if (R == 0) return TST_OK;
+    hipLaunchKernelGGL(sample_rows_kernel<T>, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, ld, (int)V,
+                       temperature, seed, step, sent, tok, row_vec_ok(logits, ld));
+    return tst_after_launch(name);
 }
 
 bool rows_ok(const tst_rows* r, bool need_anc) {
@@ -394,43 +462,32 @@ bool rows_ok(const tst_rows* r, bool need_anc) {
 }  // namespace
 
 extern "C" int tst_argmax_rows_f32(const float* logits, int64_t ld, int64_t R, int64_t V, int32_t* tok, void* stream) {
-    TST_REQUIRE(logits && tok, TST_ERR_ARG, "tst_argmax_rows_f32: null pointer");
-    TST_REQUIRE(R >= 0 && V > 0 && ld >= V && V < (1ll << 30) && R < (1ll << 31), TST_ERR_ARG, "tst_argmax_rows_f32: bad sizes");
-    if (R == 0) return TST_OK;
-    hipLaunchKernelGGL(argmax_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, ld, (int)V, tok,
-                       row_vec_ok(logits, ld));
-    return tst_after_launch("tst_argmax_rows_f32");
+    return argmax_entry<float>(logits, ld, R, V, tok, stream, "tst_argmax_rows_f32");
+}
+
+extern "C" int tst_argmax_rows_bf16(const void* logits, int64_t ld, int64_t R, int64_t V, int32_t* tok, void* stream) {
+    return argmax_entry<__bf16>((const __bf16*)logits, ld, R, V, tok, stream, "tst_argmax_rows_bf16");
 }
 
 extern "C" int tst_sample_rows_f32(const float* logits, int64_t ld, int64_t R, int64_t V, float temperature, uint32_t seed,
                                    uint32_t step, const int32_t* sent, int32_t* tok, void* stream) {
-    TST_REQUIRE(logits && sent && tok, TST_ERR_ARG, "tst_sample_rows_f32: null pointer");
-    TST_REQUIRE(R >= 0 && V > 0 && ld >= V && V < (1ll << 30) && R < (1ll << 31) && temperature > 0.0f, TST_ERR_ARG,
-                "tst_sample_rows_f32: bad sizes or temperature <= 0");
-    if (R == 0) return TST_OK;
-    hipLaunchKernelGGL(sample_rows_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, ld, (int)V,
-                       temperature, seed, step, sent, tok, row_vec_ok(logits, ld));
-    return tst_after_launch("tst_sample_rows_f32");
+    return sample_entry<float>(logits, ld, R, V, temperature, seed, step, sent, tok, stream, "tst_sample_rows_f32");
+}
+
+extern "C" int tst_sample_rows_bf16(const void* logits, int64_t ld, int64_t R, int64_t V, float temperature, uint32_t seed,
+                                    uint32_t step, const int32_t* sent, int32_t* tok, void* stream) {
+    return sample_entry<__bf16>((const __bf16*)logits, ld, R, V, temperature, seed, step, sent, tok, stream,
+                                "tst_sample_rows_bf16");
 }
 
 extern "C" int tst_logsoftmax_topk_f32(const float* logits, int64_t ld, int64_t R, int64_t V, int64_t k, float* top_val,
                                        int32_t* top_idx, float* lse, void* stream) {
-    TST_REQUIRE(logits && top_val && top_idx && lse, TST_ERR_ARG, "tst_logsoftmax_topk_f32: null pointer");
-    TST_REQUIRE(R >= 0 && V > 0 && ld >= V && V < (1ll << 30) && R < (1ll << 31), TST_ERR_ARG,
-                "tst_logsoftmax_topk_f32: bad sizes");
-    TST_REQUIRE(k >= 1 && k <= 8 && k <= V, TST_ERR_UNSUPPORTED, "tst_logsoftmax_topk_f32: need 1 <= k <= min(8, V)");
-    if (R == 0) return TST_OK;
-    hipStream_t st = (hipStream_t)stream;
-    switch (k) {
-        case 1: return launch_topk<1>(logits, ld, R, V, top_val, top_idx, lse, st);
-        case 2: return launch_topk<2>(logits, ld, R, V, top_val, top_idx, lse, st);
-        case 3: return launch_topk<3>(logits, ld, R, V, top_val, top_idx, lse, st);
-        case 4: return launch_topk<4>(logits, ld, R, V, top_val, top_idx, lse, st);
-        case 5: return launch_topk<5>(logits, ld, R, V, top_val, top_idx, lse, st);
-        case 6: return launch_topk<6>(logits, ld, R, V, top_val, top_idx, lse, st);
-        case 7: return launch_topk<7>(logits, ld, R, V, top_val, top_idx, lse, st);
-        default: return launch_topk<8>(logits, ld, R, V, top_val, top_idx, lse, st);
-    }
+    return topk_entry<float>(logits, ld, R, V, k, top_val, top_idx, lse, stream, "tst_logsoftmax_topk_f32");
+}
+
+extern "C" int tst_logsoftmax_topk_bf16(const void* logits, int64_t ld, int64_t R, int64_t V, int64_t k, float* top_val,
+                                        int32_t* top_idx, float* lse, void* stream) {
+    return topk_entry<__bf16>((const __bf16*)logits, ld, R, V, k, top_val, top_idx, lse, stream, "tst_logsoftmax_topk_bf16");
 }
 
 extern "C" int tst_greedy_select(const int32_t* argmax_tok, int64_t n_rows, int32_t eos, int32_t* sel_parent,

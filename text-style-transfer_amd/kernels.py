@@ -1,7 +1,8 @@
 """Thin wrappers that launch the HIP kernels of ``libtst_hip.so`` on torch device tensors.
 
 torch is used for device memory and the current stream only; every function below is one C-ABI call.
-Tensors must be contiguous fp32 / int32 on the GPU; outputs are written into caller-provided tensors.
+Tensors must be contiguous fp32 / bf16 / int32 on the GPU; outputs are written into caller-provided tensors.
+Where a kernel exists for fp32 and bf16 storage the wrapper picks the entry point by the tensors' dtype.
 """
 import torch
 
@@ -35,10 +36,36 @@ def embed_posadd(tok, emb, pe, scale, out, n_rows, pos=None):
 
 
 def layernorm(x, gamma, beta, out, n_rows, eps=1e-5):
-    _chk(x, torch.float32, 'x'); _chk(out, torch.float32, 'out'); _chk(gamma, torch.float32, 'gamma'); _chk(beta, torch.float32, 'beta')
+    """out = LayerNorm(x); ``out`` is fp32, or bf16 when it feeds a bf16 GEMM"""
+    _chk(x, torch.float32, 'x'); _chk(gamma, torch.float32, 'gamma'); _chk(beta, torch.float32, 'beta')
+    _chk(out, out.dtype if out.dtype == torch.bfloat16 else torch.float32, 'out')
     d = x.shape[1]
     assert gamma.numel() == d and beta.numel() == d and out.shape[1] == d
-    call('tst_layernorm_f32', _p(x), _p(gamma), _p(beta), float(eps), _p(out), n_rows, d, _stream())
+    name = 'tst_layernorm_f32_bf16' if out.dtype == torch.bfloat16 else 'tst_layernorm_f32'
+    call(name, _p(x), _p(gamma), _p(beta), float(eps), _p(out), n_rows, d, _stream())
+
+
+def add_rows(x, z, idx, n_rows):
+    """x[r] += z[idx[r]]"""
+    _chk(x, torch.float32, 'x'); _chk(z, torch.float32, 'z'); _chk(idx, torch.int32, 'idx')
+    assert x.shape[1] == z.shape[1] and x.shape[0] >= n_rows and idx.shape[0] >= n_rows
+    call('tst_add_rows_f32', _p(x), _p(z), _p(idx), n_rows, x.shape[1], _stream())
+
+
+def gemm_bf16(a, w, bias, out, n_rows, n_cols=None, res=None, act=0):
+    """out[:n_rows, :N] = epilogue(a[:n_rows] @ w[:N].T + bias); ``a`` [rows, K] and ``w`` [N, K] are bf16 (``w`` is an
+    nn.Linear weight as stored); ``out`` is bf16 or fp32, ``res`` fp32; 2-D views with unit inner stride."""
+    for t, nm, dt in ((a, 'a', torch.bfloat16), (w, 'w', torch.bfloat16), (res, 'res', torch.float32), (bias, 'bias', torch.float32)):
+        if t is not None and not (t.is_cuda and t.dtype == dt and t.stride(-1) == 1):
+            raise ValueError('%s must be a %s GPU tensor with unit inner stride' % (nm, dt))
+    if not (out.is_cuda and out.dtype in (torch.bfloat16, torch.float32) and out.stride(-1) == 1):
+        raise ValueError('out must be a bf16 or fp32 GPU tensor with unit inner stride')
+    K = a.shape[1]
+    N = w.shape[0] if n_cols is None else n_cols
+    assert w.shape[1] == K and w.shape[0] >= N and out.shape[1] >= N and a.shape[0] >= n_rows and out.shape[0] >= n_rows
+    assert bias is None or bias.numel() >= N
+    call('tst_gemm_mfma_bf16', _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(res), 0 if res is None else res.stride(0),
+         _p(out), out.stride(0), n_rows, N, K, int(act), int(out.dtype == torch.bfloat16), _stream())
 
 
 def gemm(a, wt, bias, out, n_rows, n_cols=None, res=None, act=0):
@@ -56,18 +83,20 @@ def gemm(a, wt, bias, out, n_rows, n_cols=None, res=None, act=0):
 
 
 def attn_self_step(cache, anc, pos, out, n_rows, d, heads):
-    """cache [n_pos, slab_rows, 3d]; anc [rows, T] int32"""
-    _chk(cache, torch.float32, 'cache'); _chk(anc, torch.int32, 'anc'); _chk(out, torch.float32, 'out')
+    """cache [n_pos, slab_rows, 3d] fp32 or bf16 (``out`` of the same type); anc [rows, T] int32"""
+    _chk(cache, cache.dtype if cache.dtype == torch.bfloat16 else torch.float32, 'cache'); _chk(anc, torch.int32, 'anc')
+    _chk(out, cache.dtype, 'out')
     assert cache.shape[2] == 3 * d and pos < cache.shape[0] and out.shape[1] == d
-    call('tst_attn_self_step_f32', _p(cache), cache.shape[1], _p(anc), anc.shape[1], pos, _p(out), n_rows, d, heads, _stream())
+    call('tst_attn_self_step_bf16' if cache.dtype == torch.bfloat16 else 'tst_attn_self_step_f32', _p(cache), cache.shape[1], _p(anc), anc.shape[1], pos, _p(out), n_rows, d, heads, _stream())
 
 
 def attn_cross_step(q, kv, mask, sent, out, n_rows, d, heads):
     """q [rows, d]; kv [n_sent, S, 2d]; mask [n_sent, S] uint8 or None; sent [rows] int32"""
-    _chk(q, torch.float32, 'q'); _chk(kv, torch.float32, 'kv'); _chk(mask, torch.uint8, 'mask'); _chk(sent, torch.int32, 'sent')
-    _chk(out, torch.float32, 'out')
+    dt = torch.bfloat16 if q.dtype == torch.bfloat16 else torch.float32
+    _chk(q, dt, 'q'); _chk(kv, dt, 'kv'); _chk(mask, torch.uint8, 'mask'); _chk(sent, torch.int32, 'sent')
+    _chk(out, dt, 'out')
     assert kv.shape[2] == 2 * d and (mask is None or tuple(mask.shape) == tuple(kv.shape[:2]))
-    call('tst_attn_cross_step_f32', _p(q), _p(kv), _p(mask), _p(sent), kv.shape[1], _p(out), n_rows, d, heads, _stream())
+    call('tst_attn_cross_step_bf16' if dt == torch.bfloat16 else 'tst_attn_cross_step_f32', _p(q), _p(kv), _p(mask), _p(sent), kv.shape[1], _p(out), n_rows, d, heads, _stream())
 
 
 def gru_cell_step(gi, gh, h, h_out, n_rows):
@@ -84,23 +113,26 @@ def gather_rows(src, idx, dst, n_rows):
     call('tst_gather_rows_f32', _p(src), _p(idx), _p(dst), n_rows, src.shape[1], _stream())
 
 
+def _logits_suffix(logits):
+    if not (logits.is_cuda and logits.dtype in (torch.float32, torch.bfloat16) and logits.stride(-1) == 1):
+        raise ValueError('logits must be an fp32 or bf16 GPU tensor with unit inner stride')
+    return '_bf16' if logits.dtype == torch.bfloat16 else '_f32'
+
+
 def argmax_rows(logits, n_rows, n_cols, out_tok):
     _chk(out_tok, torch.int32, 'out_tok')
-    assert logits.is_cuda and logits.dtype == torch.float32 and logits.stride(-1) == 1
-    call('tst_argmax_rows_f32', _p(logits), logits.stride(0), n_rows, n_cols, _p(out_tok), _stream())
+    call('tst_argmax_rows' + _logits_suffix(logits), _p(logits), logits.stride(0), n_rows, n_cols, _p(out_tok), _stream())
 
 
 def sample_rows(logits, n_rows, n_cols, temperature, seed, step, sent, out_tok):
     _chk(out_tok, torch.int32, 'out_tok'); _chk(sent, torch.int32, 'sent')
-    assert logits.is_cuda and logits.dtype == torch.float32 and logits.stride(-1) == 1
-    call('tst_sample_rows_f32', _p(logits), logits.stride(0), n_rows, n_cols, float(temperature), int(seed) & 0xffffffff,
+    call('tst_sample_rows' + _logits_suffix(logits), _p(logits), logits.stride(0), n_rows, n_cols, float(temperature), int(seed) & 0xffffffff,
          int(step), _p(sent), _p(out_tok), _stream())
 
 
 def logsoftmax_topk(logits, n_rows, n_cols, k, top_val, top_idx, lse):
     _chk(top_val, torch.float32, 'top_val'); _chk(top_idx, torch.int32, 'top_idx'); _chk(lse, torch.float32, 'lse')
-    assert logits.is_cuda and logits.dtype == torch.float32 and logits.stride(-1) == 1
-    call('tst_logsoftmax_topk_f32', _p(logits), logits.stride(0), n_rows, n_cols, k, _p(top_val), _p(top_idx), _p(lse),
+    call('tst_logsoftmax_topk' + _logits_suffix(logits), _p(logits), logits.stride(0), n_rows, n_cols, k, _p(top_val), _p(top_idx), _p(lse),
          _stream())
 
 

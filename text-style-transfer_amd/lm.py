@@ -1,0 +1,198 @@
+"""Transformer language model / auto-encoder decoder conditioned on a vector ``z``, stepped on the HIP kernels.
+
+Call surface as used by the reference (``/root/reference/src/trainers/lm_trainer.py:54,72-74,86``):
+``TransformerLM(hp.transformer, vocab)``, ``lm(z [B, model_size], x [B, T]) -> [B, T, V]`` raw logits and
+``lm.inference(src, vocab, eos_token=..., max_len=...)``; the only size the reference's config gives is
+``model_size: 512`` (``/root/reference/experiments/lm/config.yml:25-26``).  The model source of the reference
+is an absent submodule; the architecture is this build's own: decoder-only pre-norm layers (self-attention
++ feed-forward), input ``embedding * sqrt(d) + position + z`` (the conditioning vector is added at every
+position), final LayerNorm, linear output to raw logits.  Defaults: 6 layers, 8 heads, d_ff = 4 d.
+
+``dtype='bf16'`` stores weights, GEMM operands, the q|k|v cache and the logits in bf16 (fp32 accumulation on
+the bf16 matrix cores, fp32 residual stream, LayerNorm statistics, softmax and scores); ``'fp32'`` runs the
+fixed-order fp32 kernels.
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+from . import kernels as K
+from .transformer import HP, HipModule, _t, sinusoid_table
+
+
+class TransformerLM(HipModule):
+    def __init__(self, hp, vocab, device='cuda', dtype=None):
+        super().__init__(device)
+        hp = HP(hp)
+        d = hp.get('model_size', hp.get('d_model'))
+        if d is None:
+            raise KeyError('hp.model_size')
+        self.hp, self.vocab = hp, vocab
+        self.d, self.V = d, len(vocab)
+        self.n_layers, self.heads = hp.get('n_layers', 6), hp.get('n_heads', 8)
+        self.d_ff, self.pe_max_len = hp.get('d_ff', 4 * d), hp.get('pe_max_len', 512)
+        self.dtype = dtype or hp.get('dtype', 'fp32')
+        if self.dtype not in ('fp32', 'bf16'):
+            raise ValueError("dtype must be 'fp32' or 'bf16'")
+        if d % self.heads or (d // self.heads) % 4 or d % 8 or self.d_ff % 8:
+            raise ValueError('model_size / n_heads must be a multiple of 4, model_size and d_ff multiples of 8')
+        self.event_log = None  # set to a list to collect (start, end, flops) of every vocabulary projection
+        s = 1.0 / math.sqrt(d)
+        self._add('embed.weight', (self.V, d), std=s)
+        for i in range(self.n_layers):
+            p = 'layers.%d.' % i
+            self._add(p + 'ln1.weight', (d,), fill=1.0)
+            self._add(p + 'ln1.bias', (d,), fill=0.0)
+            for n in 'qkvo':
+                self._add(p + 'self_attn.' + n + '.weight', (d, d), std=s)
+                self._add(p + 'self_attn.' + n + '.bias', (d,), fill=0.0)
+            self._add(p + 'ln2.weight', (d,), fill=1.0)
+            self._add(p + 'ln2.bias', (d,), fill=0.0)
+            self._add(p + 'ff.w1.weight', (self.d_ff, d), std=s)
+            self._add(p + 'ff.w1.bias', (self.d_ff,), fill=0.0)
+            self._add(p + 'ff.w2.weight', (d, self.d_ff), std=1.0 / math.sqrt(self.d_ff))
+            self._add(p + 'ff.w2.bias', (d,), fill=0.0)
+        self._add('ln.weight', (d,), fill=1.0)
+        self._add('ln.bias', (d,), fill=0.0)
+        self._add('out.weight', (self.V, d), std=s)
+        self._add('out.bias', (self.V,), fill=0.0)
+        self._params['pe'] = sinusoid_table(self.pe_max_len, d).to(self.device)
+
+    def prepared(self):
+        """Weights in kernel layout: fp32 -> transposed [in, out]; bf16 -> as stored [out, in], rounded to bf16."""
+        if self._prepared is None:
+            P, W = self._params, {}
+            bf = self.dtype == 'bf16'
+            lay = (lambda w: w.to(torch.bfloat16).contiguous()) if bf else _t
+            W['emb'], W['pe'] = P['embed.weight'].contiguous(), P['pe'].contiguous()
+            W['layers'] = []
+            for i in range(self.n_layers):
+                p = 'layers.%d.' % i
+                sa = p + 'self_attn.'
+                L = {'ln1': (P[p + 'ln1.weight'], P[p + 'ln1.bias']), 'ln2': (P[p + 'ln2.weight'], P[p + 'ln2.bias'])}
+                L['wqkv'] = lay(torch.cat([P[sa + 'q.weight'], P[sa + 'k.weight'], P[sa + 'v.weight']], 0))
+                L['bqkv'] = torch.cat([P[sa + 'q.bias'], P[sa + 'k.bias'], P[sa + 'v.bias']]).contiguous()
+                L['wo'], L['bo'] = lay(P[sa + 'o.weight']), P[sa + 'o.bias']
+                L['w1'], L['b1'] = lay(P[p + 'ff.w1.weight']), P[p + 'ff.w1.bias']
+                L['w2'], L['b2'] = lay(P[p + 'ff.w2.weight']), P[p + 'ff.w2.bias']
+                W['layers'].append(L)
+            W['ln'] = (P['ln.weight'], P['ln.bias'])
+            W['wout'], W['bout'] = lay(P['out.weight']), P['out.bias']
+            self._prepared = W
+        return self._prepared
+
+    # ---- step-wise protocol used by the decode loop -------------------------------------------------
+    def session(self, z, enc_mask=None, rows_per_sentence=1, max_len=None):
+        return TransformerLMSession(self, z, rows_per_sentence, max_len if max_len is not None else self.pe_max_len)
+
+    # ---- reference call protocol: whole-prefix logits ------------------------------------------------
+    def __call__(self, z, x):
+        """z [B, model_size], x [B, t] ids -> raw logits [B, t, V] (every position attends to its prefix);
+        evaluated as t incremental steps over the KV cache."""
+        B, t = x.shape
+        sess = self.session(z, None, 1, t)
+        rows = _identity_rows(B, t, self.device)
+        out = torch.empty((B, t, self.V), dtype=torch.float32, device=self.device)
+        x32 = x.to(device=self.device, dtype=torch.int32)
+        for p in range(t):
+            rows.tok.copy_(x32[:, p])
+            out[:, p] = sess.step(rows, B, p)[:B, :self.V]
+        return out
+
+    def inference(self, src, vocab=None, eos_token='<eos>', max_len=100):
+        """Greedy continuation of one token sequence ``src`` (1-D ids) with z = 0, as the reference's
+        validation calls it (``/root/reference/src/trainers/lm_trainer.py:86``): the prefix is fed through
+        the KV cache, then up to ``max_len`` tokens are generated until ``eos_token``.  Returns the
+        generated ids (prefix and EOS not included) as a 1-D LongTensor.  What the absent reference model
+        returns exactly is unknown; this format is this build's choice."""
+        vocab = vocab or self.vocab
+        eos = vocab.stoi[eos_token]
+        src = torch.as_tensor(src).reshape(-1).to(device=self.device, dtype=torch.int32)
+        n_prefix = int(src.numel())
+        if n_prefix < 1:
+            raise ValueError('inference needs at least one prefix token')
+        total = n_prefix + max_len
+        sess = self.session(torch.zeros((1, self.d), device=self.device), None, 1, total)
+        rows = _identity_rows(1, total, self.device)
+        am = torch.zeros(1, dtype=torch.int32, device=self.device)
+        out = []
+        for p in range(total - 1):
+            rows.tok.copy_(src[p:p + 1] if p < n_prefix else am)
+            logits = sess.step(rows, 1, p)
+            if p >= n_prefix - 1:
+                K.argmax_rows(logits, 1, self.V, am)
+                tok = int(am.item())
+                if tok == eos or len(out) >= max_len:
+                    break
+                out.append(tok)
+        return torch.tensor(out, dtype=torch.long, device=self.device)
+
+
+def _identity_rows(B, T, device):
+    rows = K.RowState(B, max(T, 1), device, True, 0)
+    ar = torch.arange(B, dtype=torch.int32, device=device)
+    rows.sent.copy_(ar)
+    rows.anc.copy_(ar.unsqueeze(1).expand(B, max(T, 1)))
+    return rows
+
+
+class TransformerLMSession:
+    """Per-batch decode state of a ``TransformerLM``: the conditioning vectors, the self-attention q|k|v cache
+    [layer][position][row slot][3d] (addressed through the ancestor table, so beam reorders move nothing)
+    and work buffers."""
+    needs_anc = True
+
+    def __init__(self, lm, z, k, max_len):
+        self.lm, self.V = lm, lm.V
+        W = lm.prepared()
+        dev = lm.device
+        if max_len > W['pe'].shape[0]:
+            raise ValueError('max_len %d exceeds pe_max_len %d' % (max_len, W['pe'].shape[0]))
+        z = z.to(device=dev, dtype=torch.float32).contiguous()
+        if z.dim() != 2 or z.shape[1] != lm.d:
+            raise ValueError('z must be [B, model_size=%d], got %s' % (lm.d, tuple(z.shape)))
+        self.z = z
+        B, d = z.shape
+        R = B * k
+        self.R = R
+        act = torch.bfloat16 if lm.dtype == 'bf16' else torch.float32
+        f32 = dict(dtype=torch.float32, device=dev)
+        lo = dict(dtype=act, device=dev)
+        self.cache = [torch.empty((max_len, R, 3 * d), **lo) for _ in W['layers']]
+        self.x = torch.empty((R, d), **f32)
+        self.h = torch.empty((R, d), **lo)
+        self.a = torch.empty((R, d), **lo)
+        self.ff = torch.empty((R, lm.d_ff), **lo)
+        self.logits = torch.empty((R, (lm.V + 7) // 8 * 8), **lo)
+        self.scale = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
+        self.gemm = K.gemm_bf16 if lm.dtype == 'bf16' else K.gemm
+
+    def reorder(self, row_parent, n_rows, identity):
+        pass  # the KV cache is addressed through the ancestor table; nothing moves
+
+    def step(self, rows, n, t):
+        lm, W, gemm = self.lm, self.lm.prepared(), self.gemm
+        d, H = lm.d, lm.heads
+        x, h, a, ff = self.x, self.h, self.a, self.ff
+        K.embed_posadd(rows.tok, W['emb'], W['pe'][t], self.scale, x, n)
+        K.add_rows(x, self.z, rows.sent, n)
+        for li, L in enumerate(W['layers']):
+            K.layernorm(x, L['ln1'][0], L['ln1'][1], h, n)
+            gemm(h, L['wqkv'], L['bqkv'], self.cache[li][t], n)
+            K.attn_self_step(self.cache[li], rows.anc, t, a, n, d, H)
+            gemm(a, L['wo'], L['bo'], x, n, res=x)
+            K.layernorm(x, L['ln2'][0], L['ln2'][1], h, n)
+            gemm(h, L['w1'], L['b1'], ff, n, act=1)
+            gemm(ff, L['w2'], L['b2'], x, n, res=x)
+        K.layernorm(x, W['ln'][0], W['ln'][1], h, n)
+        log = lm.event_log
+        if log is None:
+            gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
+        else:  # measurement aid: HIP events on the launch stream around the vocabulary projection
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
+            e1.record()
+            log.append((e0, e1, 2.0 * n * d * self.V))
+        return self.logits
