@@ -17,17 +17,18 @@ namespace {
 
 constexpr int BK = 16, GROUP_M = 16;
 
-// WT = MFMA tiles (32 x 32) per wave and dimension: the workgroup tile is (64 * WT) x (64 * WT).
-// WT = 2 (128 x 128) for large problems; WT = 1 (64 x 64) when the 128-tiling would leave CUs without work.
-template <int WT, bool FULL_K, bool HAS_RES, bool RELU>
-__global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
+// WTM x WTN = MFMA tiles (32 x 32) per wave: the workgroup tile is (64 * WTM) x (64 * WTN).
+// 2 x 4 (128 x 256: fewest LDS reads and staged bytes per MFMA) for wide outputs, 2 x 2 (128 x 128) for
+// large problems, 1 x 1 (64 x 64) when the 128-tiling would leave CUs without work.
+template <int WTM, int WTN, bool FULL_K, bool HAS_RES, bool RELU>
+__global__ __launch_bounds__(256, (WTN == 4 ? 2 : 1)) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ W, int64_t ldw,
                                                        const float* __restrict__ bias, const float* res, int64_t ldr,
                                                        float* C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
-    constexpr int BM = 64 * WT, BN = 64 * WT, LDT = BM + 4;
-    constexpr int NLD = WT;  // float4 loads per thread and operand: BM * BK / 4 / 256
-    __shared__ __attribute__((aligned(16))) float As[3][BK][LDT];
-    __shared__ __attribute__((aligned(16))) float Bs[3][BK][LDT];
+    constexpr int BM = 64 * WTM, BN = 64 * WTN, LDA = BM + 4, LDB = BN + 4;
+    constexpr int NLA = WTM, NLB = WTN;  // float4 loads per thread: BM * BK / 4 / 256 and BN * BK / 4 / 256
+    __shared__ __attribute__((aligned(16))) float As[3][BK][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[3][BK][LDB];
 
     // workgroup id -> logical tile index: consecutive ids go to different XCDs, so give every XCD a
     // contiguous range (bijective for any grid size), then walk tiles in groups of GROUP_M rows.
@@ -50,16 +51,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     // Loads are unconditional from clamped (always valid) addresses and out-of-range data is zeroed
     // afterwards: a conditional load would be compiled to a select between addresses and lose the
     // 16-byte global_load.
-    float4 ra0, ra1, rb0, rb1;  // named registers (arrays here end up in scratch memory); *1 unused when WT == 1
+    // named registers (arrays here end up in scratch memory); ra1 unused when NLA == 1, rb1..3 when NLB < 2, 4
+    float4 ra0, ra1, rb0, rb1, rb2, rb3;
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const int akq = (t & 3) * 4;
     const int bnq = (t % (BN / 4)) * 4;
     const int ar0 = t >> 2, ar1 = (t + 256) >> 2;
-    const int bk0 = t / (BN / 4), bk1 = (t + 256) / (BN / 4);
+    constexpr int BKS = 1024 / BN;  // k rows of the Wt tile covered by one round of 256 float4 loads
+    const int bk0 = t / (BN / 4), bk1 = bk0 + BKS, bk2 = bk0 + 2 * BKS, bk3 = bk0 + 3 * BKS;
     const float* a_row0 = A + (int64_t)min(m0 + ar0, M - 1) * lda;
     const float* a_row1 = A + (int64_t)min(m0 + ar1, M - 1) * lda;
     const int bcol_g = min(n0 + bnq, (int)ldw - 4);
-    ra1 = zero4; rb1 = zero4;
+    ra1 = zero4; rb1 = zero4; rb2 = zero4; rb3 = zero4;
 
 #define TST_LOAD_TILE(k0)                                                                                     \
     do {                                                                                                      \
@@ -67,14 +70,18 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         const int gkc_ = min(gk_, K - 4);                                                                     \
         ra0 = *reinterpret_cast<const float4*>(a_row0 + gkc_);                                                \
         rb0 = *reinterpret_cast<const float4*>(W + (int64_t)min((k0) + bk0, K - 1) * ldw + bcol_g);           \
-        if (NLD == 2) {                                                                                       \
-            ra1 = *reinterpret_cast<const float4*>(a_row1 + gkc_);                                            \
-            rb1 = *reinterpret_cast<const float4*>(W + (int64_t)min((k0) + bk1, K - 1) * ldw + bcol_g);       \
+        if (NLA == 2) ra1 = *reinterpret_cast<const float4*>(a_row1 + gkc_);                                  \
+        if (NLB >= 2) rb1 = *reinterpret_cast<const float4*>(W + (int64_t)min((k0) + bk1, K - 1) * ldw + bcol_g); \
+        if (NLB == 4) {                                                                                       \
+            rb2 = *reinterpret_cast<const float4*>(W + (int64_t)min((k0) + bk2, K - 1) * ldw + bcol_g);       \
+            rb3 = *reinterpret_cast<const float4*>(W + (int64_t)min((k0) + bk3, K - 1) * ldw + bcol_g);       \
         }                                                                                                     \
         if (!FULL_K) {                                                                                        \
             if (gk_ >= K) { ra0 = zero4; ra1 = zero4; }                                                       \
             if ((k0) + bk0 >= K) rb0 = zero4;                                                                 \
             if ((k0) + bk1 >= K) rb1 = zero4;                                                                 \
+            if ((k0) + bk2 >= K) rb2 = zero4;                                                                 \
+            if ((k0) + bk3 >= K) rb3 = zero4;                                                                 \
         }                                                                                                     \
     } while (0)
 #define TST_STORE_TILE(buf)                                                                                   \
@@ -82,20 +89,24 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
         As[buf][akq + 0][ar0] = ra0.x; As[buf][akq + 1][ar0] = ra0.y;                                         \
         As[buf][akq + 2][ar0] = ra0.z; As[buf][akq + 3][ar0] = ra0.w;                                         \
         *reinterpret_cast<float4*>(&Bs[buf][bk0][bnq]) = rb0;                                                 \
-        if (NLD == 2) {                                                                                       \
+        if (NLA == 2) {                                                                                       \
             As[buf][akq + 0][ar1] = ra1.x; As[buf][akq + 1][ar1] = ra1.y;                                     \
             As[buf][akq + 2][ar1] = ra1.z; As[buf][akq + 3][ar1] = ra1.w;                                     \
-            *reinterpret_cast<float4*>(&Bs[buf][bk1][bnq]) = rb1;                                             \
+        }                                                                                                     \
+        if (NLB >= 2) *reinterpret_cast<float4*>(&Bs[buf][bk1][bnq]) = rb1;                                   \
+        if (NLB == 4) {                                                                                       \
+            *reinterpret_cast<float4*>(&Bs[buf][bk2][bnq]) = rb2;                                             \
+            *reinterpret_cast<float4*>(&Bs[buf][bk3][bnq]) = rb3;                                             \
         }                                                                                                     \
     } while (0)
 
-    f32x16 acc[WT][WT];
+    f32x16 acc[WTM][WTN];
 #pragma unroll
-    for (int j = 0; j < WT; ++j) {
-        const int col = n0 + wn * 32 * WT + j * 32 + (lane & 31);
+    for (int j = 0; j < WTN; ++j) {
+        const int col = n0 + wn * 32 * WTN + j * 32 + (lane & 31);
         const float b = (bias != nullptr && col < N) ? bias[col] : 0.0f;
 #pragma unroll
-        for (int i = 0; i < WT; ++i)
+        for (int i = 0; i < WTM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = b;
     }
@@ -110,16 +121,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     TST_STORE_TILE(0);
     if (nkt > 1) TST_LOAD_TILE(BK);
     __syncthreads();
-    const int arow = wm * 32 * WT + (lane & 31), bcol = wn * 32 * WT + (lane & 31), khalf = lane >> 5;
+    const int arow = wm * 32 * WTM + (lane & 31), bcol = wn * 32 * WTN + (lane & 31), khalf = lane >> 5;
     // The MFMA operands (one float of A and of Wt per lane and 32 x 32 tile) are read from LDS one k-step
     // ahead of the MFMAs that use them, also across the mid-tile barrier and into the next tile's buffer
     // (complete since that barrier), so the LDS latency is never exposed.
-    float a_cur[WT], b_cur[WT], a_nxt[WT], b_nxt[WT];
+    float a_cur[WTM], b_cur[WTN], a_nxt[WTM], b_nxt[WTN];
 #define TST_READ_OPERANDS(av, bv, bufi, kk)                                                                   \
-    _Pragma("unroll") for (int i = 0; i < WT; ++i) {                                                          \
-        av[i] = As[bufi][(kk) + khalf][arow + 32 * i];                                                        \
-        bv[i] = Bs[bufi][(kk) + khalf][bcol + 32 * i];                                                        \
-    }
+    _Pragma("unroll") for (int i = 0; i < WTM; ++i) av[i] = As[bufi][(kk) + khalf][arow + 32 * i];            \
+    _Pragma("unroll") for (int j = 0; j < WTN; ++j) bv[j] = Bs[bufi][(kk) + khalf][bcol + 32 * j];
     int buf = 0;
     TST_READ_OPERANDS(a_cur, b_cur, buf, 0)
     for (int kt = 0; kt < nkt; ++kt) {
@@ -132,12 +141,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
                 TST_READ_OPERANDS(a_nxt, b_nxt, nbuf, 0)
             }
 #pragma unroll
-            for (int i = 0; i < WT; ++i)
+            for (int i = 0; i < WTM; ++i)
 #pragma unroll
-                for (int j = 0; j < WT; ++j)
+                for (int j = 0; j < WTN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < WT; ++i) { a_cur[i] = a_nxt[i]; b_cur[i] = b_nxt[i]; }
+            for (int i = 0; i < WTM; ++i) a_cur[i] = a_nxt[i];
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) b_cur[j] = b_nxt[j];
             if (kk == BK / 2 - 2) {
                 if (kt + 1 < nkt) {
                     TST_STORE_TILE(nbuf);
@@ -154,11 +165,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
     // tiles that lie fully inside the matrix take the unguarded path
     const bool full_tile = m0 + BM <= M && n0 + BN <= N;
 #pragma unroll
-    for (int i = 0; i < WT; ++i)
+    for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < WT; ++j) {
-            const int col = n0 + wn * 32 * WT + j * 32 + (lane & 31);
-            const int row0 = m0 + wm * 32 * WT + i * 32 + 4 * (lane >> 5);
+        for (int j = 0; j < WTN; ++j) {
+            const int col = n0 + wn * 32 * WTN + j * 32 + (lane & 31);
+            const int row0 = m0 + wm * 32 * WTM + i * 32 + 4 * (lane >> 5);
             float rv[16];
             if (full_tile) {
                 float* cp = C + (int64_t)row0 * ldc + col;
@@ -198,14 +209,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const float* __restrict__
 #undef TST_LOAD_TILE
 #undef TST_STORE_TILE
 
-template <int WT>
+template <int WTM, int WTN>
 void launch_gemm(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res, int64_t ldr,
                  float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st) {
-    constexpr int BT = 64 * WT;
-    const int64_t tiles_m = (M + BT - 1) / BT, tiles_n = (N + BT - 1) / BT;
+    constexpr int BTM = 64 * WTM, BTN = 64 * WTN;
+    const int64_t tiles_m = (M + BTM - 1) / BTM, tiles_n = (N + BTN - 1) / BTN;
     const dim3 grid((unsigned)(tiles_m * tiles_n));
 #define TST_GEMM_LAUNCH(FK, HR, RL)                                                                                    \
-    hipLaunchKernelGGL((gemm_f32_kernel<WT, FK, HR, RL>), grid, dim3(256), 0, st, A, lda, Wt, ldw, bias, res, ldr, C, ldc, \
+    hipLaunchKernelGGL((gemm_f32_kernel<WTM, WTN, FK, HR, RL>), grid, dim3(256), 0, st, A, lda, Wt, ldw, bias, res, ldr, C, ldc, \
                        (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n)
     const int variant = (K % BK == 0 ? 4 : 0) | (res != nullptr ? 2 : 0) | (act == 1 ? 1 : 0);
     switch (variant) {
@@ -238,9 +249,11 @@ extern "C" int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, i
     TST_REQUIRE(((M + 63) / 64) * ((N + 63) / 64) < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_f32: grid too large");
     // 128 x 128 tiles unless they would give fewer than two workgroups per CU (256 CUs): then 64 x 64
     const int64_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    if (big_tiles >= 512)
-        launch_gemm<2>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
+    if (big_tiles >= 4096 && N >= 2048)
+        launch_gemm<2, 4>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
+    else if (big_tiles >= 512)
+        launch_gemm<2, 2>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
     else
-        launch_gemm<1>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
+        launch_gemm<1, 1>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
     return tst_after_launch("tst_gemm_mfma_f32");
 }

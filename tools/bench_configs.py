@@ -1,0 +1,83 @@
+"""Throughput of the BASELINE configurations other than the one bench.py reports (they are parity-test cases;
+this script only measures them for the design notes).  One JSON line per case.
+
+  cfg3: GRU decoder (cyclegan sizes: E = H = 1024), 8192 sentences, greedy and beam 4, max_len 100,
+        character vocabulary (V = 128) and a 32000-word variant
+  cfg4: z-conditioned transformer LM, model_size 512, 6 layers, 8 heads, d_ff 2048, V = 32000, beam 8, bf16
+        (and the same in fp32 for comparison)
+
+Usage: python tools/bench_configs.py [cfg3|cfg4|all] [--sentences N]
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import tst_amd
+from tst_amd import synthetic
+
+
+def run(name, make_state, n_sent, repeats=3):
+    st = make_state()
+    st.decode_packed()                      # warm-up
+    torch.cuda.synchronize()
+    t0 = time.time()
+    emitted = steps = rows = 0
+    for _ in range(repeats):
+        st = make_state()
+        tok, lens, _ = st.decode_packed()
+        lens_h = lens.cpu()
+        emitted += int((lens_h.long() - 1).clamp(min=0).sum())
+        steps += st.loop.steps_done
+        rows += st.loop.rows_stepped
+    torch.cuda.synchronize()
+    dt = (time.time() - t0) / repeats
+    print(json.dumps({'case': name, 'sentences': n_sent, 'tokens_per_s': emitted / repeats / dt, 'ms_per_batch': dt * 1e3,
+                      'mean_emitted_len': emitted / repeats / n_sent, 'decode_steps': steps / repeats,
+                      'row_steps': rows / repeats, 'row_steps_per_s': rows / repeats / dt}), flush=True)
+
+
+def cfg3(n_sent, bias=None):
+    dev = torch.device('cuda', 0)
+    for V, eos_bias in ((128, 0.5), (32000, 1.0)):
+        eos_bias = eos_bias if bias is None else bias
+        vocab = tst_amd.Vocab.synthetic(V, extra=('|',))
+        model = tst_amd.RNNDecoder(1024, 1024, vocab, device=dev)
+        model.load_state_dict(synthetic.synthetic_state_dict(model, vocab.stoi['|'], eos_bias, 2.0, seed=42))
+        z = torch.randn((n_sent, 1024), generator=torch.Generator().manual_seed(1237)).to(dev)
+        for beam in (1, 4):
+            run('cfg3 GRU H=1024 V=%d beam=%d fp32 max_len=100' % (V, beam),
+                lambda: tst_amd.InferenceState({'model': model, 'inputs': z, 'vocab': vocab, 'max_len': 100, 'eos_token': '|',
+                                                'beam_size': beam}), n_sent)
+
+
+def cfg4(n_sent, bias=None):
+    dev = torch.device('cuda', 0)
+    V = 32000
+    vocab = tst_amd.Vocab.synthetic(V)
+    hp = dict(model_size=512, n_layers=6, n_heads=8, d_ff=2048, pe_max_len=64)
+    z = (0.3 * torch.randn((n_sent, 512), generator=torch.Generator().manual_seed(1238))).to(dev)
+    for dtype in ('bf16', 'fp32'):
+        lm = tst_amd.TransformerLM(tst_amd.HP(hp), vocab, device=dev, dtype=dtype)
+        lm.load_state_dict(synthetic.synthetic_state_dict(lm, 3, 5.0 if bias is None else bias, 2.0, seed=42))
+        run('cfg4 TransformerLM d=512 L=6 V=32000 beam=8 %s max_len=50' % dtype,
+            lambda: tst_amd.InferenceState({'model': lm, 'inputs': z, 'vocab': vocab, 'max_len': 50, 'beam_size': 8}), n_sent,
+            repeats=2)
+        del lm
+        torch.cuda.empty_cache()
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('which', nargs='?', default='all')
+    ap.add_argument('--sentences', type=int, default=8192)
+    ap.add_argument('--eos-bias', type=float, default=None, help='override the calibrated EOS bias (calibration runs)')
+    a = ap.parse_args()
+    if a.which in ('cfg3', 'all'):
+        cfg3(a.sentences, a.eos_bias)
+    if a.which in ('cfg4', 'all'):
+        cfg4(a.sentences, a.eos_bias)
