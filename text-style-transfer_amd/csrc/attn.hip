@@ -36,8 +36,8 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
     const T* __restrict__ base, int64_t slab_stride, const int32_t* __restrict__ anc, int64_t anc_ld,
     const T* __restrict__ qbuf, const uint8_t* __restrict__ mask, const int32_t* __restrict__ sent, int n, T* __restrict__ out,
     int64_t R, int d, int heads, int dh, float scale) {
-    __shared__ float sc[4][MAXP];
-    __shared__ int slot[4][MAXP];
+    __shared__ float sc[4][MAXP];   // score, then softmax weight, per position
+    __shared__ int slot[4][MAXP];   // SELF: cache row of every position; else: the list of unmasked positions
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t gw = (int64_t)blockIdx.x * 4 + w;
     const int64_t total = R * heads;
@@ -46,14 +46,27 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
     const int h = (int)(gw - r * heads);
     const int pos = n - 1;
 
+    // Only unmasked ("live") positions are ever loaded: a masked position has weight exactly 0 and
+    // fma(0, v, acc) == acc, so skipping it changes nothing.  nl = number of live positions (wave-uniform).
     const T* qp;
     int64_t ent = 0;
+    int nl;
     if (SELF) {
         for (int p = lane; p < n; p += 64) slot[w][p] = (p < pos) ? anc[r * anc_ld + p] : (int)r;
         qp = base + (int64_t)pos * slab_stride + r * 3 * d + h * dh;
+        nl = n;
     } else {
         ent = sent[r];
         qp = qbuf + r * d + h * dh;
+        nl = 0;
+        for (int p0 = 0; p0 < n; p0 += 64) {
+            const int p = p0 + lane;
+            const bool live = p < n && (mask == nullptr || mask[ent * n + p] != 0);
+            const unsigned long long bal = __ballot(live);
+            if (live) slot[w][nl + __popcll(bal & ((1ull << lane) - 1ull))] = p;
+            else if (p < n) sc[w][p] = -INFINITY;
+            nl += __popcll(bal);
+        }
     }
     const int j = lane & 15, g = lane >> 4;
     float4 qv[NCH];
@@ -64,34 +77,38 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
     }
     __syncthreads();
 
-    auto krow = [&](int p) -> const T* {
-        if (SELF) return base + (int64_t)p * slab_stride + (int64_t)slot[w][p] * 3 * d + d + h * dh;
-        return base + (ent * n + p) * 2 * (int64_t)d + h * dh;
+    // key row of the i-th live position; the value row follows d elements later
+    auto krow = [&](int i) -> const T* {
+        if (SELF) return base + (int64_t)i * slab_stride + (int64_t)slot[w][i] * 3 * d + d + h * dh;
+        return base + (ent * n + slot[w][i]) * 2 * (int64_t)d + h * dh;
     };
-    auto vrow = [&](int p) -> const T* { return krow(p) + d; };
 
-    // scores
-    for (int p0 = 0; p0 < n; p0 += 4) {
-        const int p = p0 + g;
-        float part = 0.0f;
-        bool live = p < n;
-        if (!SELF && live && mask != nullptr && mask[ent * n + p] == 0) live = false;
-        if (live) {
-            const T* kp = krow(p);
+    // scores: 16 lanes per position, 4 positions per pass, 4 passes in flight (independent loads)
+    for (int i0 = 0; i0 < nl; i0 += 16) {
+        float part[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const T* kp = krow(min(i0 + 4 * u + g, nl - 1));
+            float acc = 0.0f;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int ch = j + 16 * c;
                 if (ch * 4 < dh) {
                     const float4 kv = ld4(kp + 4 * ch);
-                    part = __builtin_fmaf(qv[c].x, kv.x, part);
-                    part = __builtin_fmaf(qv[c].y, kv.y, part);
-                    part = __builtin_fmaf(qv[c].z, kv.z, part);
-                    part = __builtin_fmaf(qv[c].w, kv.w, part);
+                    acc = __builtin_fmaf(qv[c].x, kv.x, acc);
+                    acc = __builtin_fmaf(qv[c].y, kv.y, acc);
+                    acc = __builtin_fmaf(qv[c].z, kv.z, acc);
+                    acc = __builtin_fmaf(qv[c].w, kv.w, acc);
                 }
             }
+            part[u] = acc;
         }
-        part = group16_sum_butterfly(part);
-        if (j == 0 && p < n) sc[w][p] = live ? part * scale : -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 4 * u + g;
+            const float tot = group16_sum_butterfly(part[u]);
+            if (j == 0 && i < nl) sc[w][SELF ? i : slot[w][i]] = tot * scale;
+        }
     }
     __syncthreads();
 
@@ -121,30 +138,33 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
     }
     __syncthreads();
 
-    // weighted value sum, positions ascending
+    // weighted value sum over the live positions in ascending order, 8 loads in flight per lane
     T* orow = out + r * d + h * dh;
     for (int c0 = lane * VEC; c0 < dh; c0 += 64 * VEC) {
         float acc[VEC];
 #pragma unroll
         for (int e = 0; e < VEC; ++e) acc[e] = 0.0f;
-#pragma unroll 4
-        for (int p = 0; p < n; ++p) {
-            const float wp = sc[w][p];
-            if (wp == 0.0f) continue;  // padding (or underflow): fma(0, v, acc) == acc; wave-uniform branch
-            const T* vp = vrow(p) + c0;
-            if (VEC == 4) {
-                const float4 v = ld4(vp);
-                acc[0] = __builtin_fmaf(wp, v.x, acc[0]);
-                acc[1 % VEC] = __builtin_fmaf(wp, v.y, acc[1 % VEC]);
-                acc[2 % VEC] = __builtin_fmaf(wp, v.z, acc[2 % VEC]);
-                acc[3 % VEC] = __builtin_fmaf(wp, v.w, acc[3 % VEC]);
-            } else if (VEC == 2) {
-                const float2 v = ld2(vp);
-                acc[0] = __builtin_fmaf(wp, v.x, acc[0]);
-                acc[1 % VEC] = __builtin_fmaf(wp, v.y, acc[1 % VEC]);
-            } else {
-                acc[0] = __builtin_fmaf(wp, ld1(vp), acc[0]);
+        for (int i0 = 0; i0 < nl; i0 += 8) {
+            float wgt[8], v[8][VEC];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u, nl - 1);
+                wgt[u] = i0 + u < nl ? sc[w][SELF ? i : slot[w][i]] : 0.0f;   // beyond the list: weight 0, no effect
+                const T* vp = krow(i) + d + c0;
+                if (VEC == 4) {
+                    const float4 x = ld4(vp);
+                    v[u][0] = x.x; v[u][1 % VEC] = x.y; v[u][2 % VEC] = x.z; v[u][3 % VEC] = x.w;
+                } else if (VEC == 2) {
+                    const float2 x = ld2(vp);
+                    v[u][0] = x.x; v[u][1 % VEC] = x.y;
+                } else {
+                    v[u][0] = ld1(vp);
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int e = 0; e < VEC; ++e) acc[e] = __builtin_fmaf(wgt[u], v[u][e], acc[e]);
         }
 #pragma unroll
         for (int e = 0; e < VEC; ++e) st1(orow + c0 + e, acc[e]);

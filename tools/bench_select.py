@@ -36,6 +36,7 @@ def timeit(fn, n=7):
 
 gb = rows * V * 4 / 1e9
 ms = timeit(lambda: K.argmax_rows(x, rows, V, tok))
+xb = x.to(torch.bfloat16)
 print('argmax_rows          %.3f ms  %.2f TB/s' % (ms, gb / ms))
 for k in (1, 4, 8):
     tv = torch.empty((rows, k), device='cuda')
@@ -47,3 +48,8 @@ print('sample_rows          %.3f ms  %.2f TB/s' % (ms, gb / ms))
 y = torch.empty_like(x)
 ms = timeit(lambda: y.copy_(x))
 print('torch copy (r+w)     %.3f ms  %.2f TB/s (read+write bytes)' % (ms, 2 * gb / ms))
+for k in (4, 8):
+    tv = torch.empty((rows, k), device='cuda')
+    ti = torch.empty((rows, k), dtype=torch.int32, device='cuda')
+    ms = timeit(lambda: K.logsoftmax_topk(xb, rows, V, k, tv, ti, lse))
+    print('logsoftmax_topk bf16 k=%d  %.3f ms  %.2f TB/s' % (k, ms, gb / 2 / ms))
