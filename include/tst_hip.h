@@ -111,29 +111,9 @@ int tst_sample_rows_f32(const float* logits, int64_t ld, int64_t R, int64_t V, f
                         uint32_t step, const int32_t* sent, int32_t* tok, void* stream);
 
 /* Per row: lse[r] = log sum exp(logits[r]) and the k largest logits (value descending, index ascending),
- * 1 <= k <= 8, k <= V.  Feeds tst_beam_merge (the reference has no beam search; build-defined).
- * The log-sum-exp has one fixed definition: blocks of 16 consecutive logits give (m_b, s_b) = (max, sum of
- * exp(x - m_b) by the xor-butterfly 1, 2, 4, 8); 64 accumulators take the blocks q, q + 64, ... with the online
- * update m' = max(m, m_b), a = a * exp(m - m') + s_b * exp(m_b - m'); lse = M + log(butterfly sum of
- * a_q * exp(m_q - M)).  One launch, one pass over the logits. */
+ * 1 <= k <= 8, k <= V.  Feeds tst_beam_merge (the reference has no beam search; build-defined). */
 int tst_logsoftmax_topk_f32(const float* logits, int64_t ld, int64_t R, int64_t V, int64_t k, float* top_val,
                             int32_t* top_idx, float* lse, void* stream);
-
-/* The vocabulary projection with the log-sum-exp partials computed in its epilogue: logits = bias + A * Wt as
- * tst_gemm_mfma_f32 (no activation, no residual) and parts[m][ceil(N / 16)][2] = the (m_b, s_b) pairs of every
- * row, taken from the accumulators before they are stored (one DPP row of 16 lanes per block).  The logits are
- * still written; the selection that follows (tst_topk_from_parts_f32) reads only the partials and the few
- * blocks that can hold a top-k element.  Same results as tst_gemm_mfma_f32 + tst_logsoftmax_topk_f32, bit for
- * bit.  On MI355X the exponentials cost the matrix-core-bound GEMM more than the HBM-bound selection pass saves
- * (they are free there, hidden behind the loads), so the decode loop uses the two-kernel form by default. */
-int tst_gemm_vocab_lse_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, float* logits,
-                           int64_t ldc, float* parts, int64_t M, int64_t N, int64_t K, void* stream);
-
-/* Finishes tst_gemm_vocab_lse_f32: lse and the k largest
- * logits of every row from the partials, one wave per row; reads back only blocks with m_b >= the k-th
- * largest accumulator maximum.  k = 1 gives the arg-max token (first maximal index) in top_idx. */
-int tst_topk_from_parts_f32(const float* logits, int64_t ld, const float* parts, int64_t R, int64_t V, int64_t k,
-                            float* top_val, int32_t* top_idx, float* lse, void* stream);
 
 /* The three selection kernels on bf16 logits (ld in elements; rows 16-byte aligned when ld % 8 == 0). */
 int tst_argmax_rows_bf16(const void* logits, int64_t ld, int64_t R, int64_t V, int32_t* tok, void* stream);
@@ -141,8 +121,6 @@ int tst_sample_rows_bf16(const void* logits, int64_t ld, int64_t R, int64_t V, f
                          uint32_t step, const int32_t* sent, int32_t* tok, void* stream);
 int tst_logsoftmax_topk_bf16(const void* logits, int64_t ld, int64_t R, int64_t V, int64_t k, float* top_val,
                              int32_t* top_idx, float* lse, void* stream);
-int tst_topk_from_parts_bf16(const void* logits, int64_t ld, const float* parts, int64_t R, int64_t V, int64_t k,
-                             float* top_val, int32_t* top_idx, float* lse, void* stream);
 
 /* Decode-loop state.  All arrays are device memory owned by the caller; "cur" arrays are read, "nxt"
  * arrays are written (ping-pong).  Rows of one sentence are contiguous (k rows per sentence).

@@ -234,66 +234,42 @@ void orc_argmax_rows(const float* x, int64_t ld, int64_t R, int64_t V, int32_t* 
     }
 }
 
-/* Canonical log-sum-exp of a row.  The same definition is computed by the stand-alone selection kernel and by
- * the vocabulary GEMM's epilogue followed by the finishing kernel, so that both give the same bits:
- *  - blocks of 16 consecutive elements (elements at or beyond V count as -inf):
- *      m_b = max of the block;  s_b = sum of exp(x - m_b) by an xor-butterfly with offsets 1, 2, 4, 8;
- *  - 64 accumulators; accumulator q takes the blocks q, q + 64, q + 128, ... in this order with the online update
- *      m' = max(m_q, m_b);  a_q = a_q * exp(m_q - m') + s_b * exp(m_b - m');  m_q = m';
- *  - M = max_q m_q;  total = xor-butterfly (32, 16, ..., 1) over q of a_q * exp(m_q - M);  lse = M + log(total).
- * orc_lse_parts writes the (m_b, s_b) pairs, [R][ceil(V / 16)][2]. */
-static void block_part(const float* xr, int64_t b, int64_t V, float* m_out, float* s_out) {
-    float e[16], t[16];
-    float m = -INFINITY;
-    for (int i = 0; i < 16; ++i) {
-        int64_t idx = 16 * b + i;
-        e[i] = idx < V ? xr[idx] : -INFINITY;
-        m = fmaxf(m, e[i]);
-    }
-    for (int i = 0; i < 16; ++i) e[i] = orc_exp(e[i] - m);
-    for (int off = 1; off < 16; off <<= 1) {
-        for (int i = 0; i < 16; ++i) t[i] = e[i] + e[i ^ off];
-        for (int i = 0; i < 16; ++i) e[i] = t[i];
-    }
-    *m_out = m;
-    *s_out = e[0];
-}
-
-void orc_lse_parts(const float* x, int64_t ld, int64_t R, int64_t V, float* parts) {
-    const int64_t nb = (V + 15) / 16;
-#pragma omp parallel for
-    for (int64_t r = 0; r < R; ++r)
-        for (int64_t b = 0; b < nb; ++b) block_part(x + r * ld, b, V, parts + (r * nb + b) * 2, parts + (r * nb + b) * 2 + 1);
-}
-
-static float lse_from_parts(const float* parts, int64_t nb) {
-    float mq[64], aq[64];
-    for (int q = 0; q < 64; ++q) { mq[q] = -INFINITY; aq[q] = 0.0f; }
-    for (int64_t b = 0; b < nb; ++b) {
-        const int q = (int)(b & 63);
-        const float mb = parts[2 * b], sb = parts[2 * b + 1];
-        const float mn = fmaxf(mq[q], mb);
-        aq[q] = aq[q] * orc_exp(mq[q] - mn) + sb * orc_exp(mb - mn);
-        mq[q] = mn;
-    }
-    float M = mq[0];
-    for (int q = 1; q < 64; ++q) if (mq[q] > M) M = mq[q];
-    float p[64];
-    for (int q = 0; q < 64; ++q) p[q] = aq[q] * orc_exp(mq[q] - M);
-    return M + orc_log(sum_butterfly(p, 64));
-}
-
-/* per row: the canonical lse and the k largest logits (value desc, index asc). */
+/* per row: lse = log sum exp(x), computed in one pass by 256 interleaved partial states (m_l, s_l).
+ * Chunk c = elements 4c..4c+3 (elements beyond V count as -inf).  Partial l consumes its chunks
+ * l, l + 256, l + 512, ... in groups of four: with the group's 16 values x_0..x_15 in ascending index order
+ *   m' = max(m, x_0..x_15);  s = s * exp(m - m');  s += exp(x_0 - m'); ...; s += exp(x_15 - m');  m = m'.
+ * Then M = max_l m_l, t_l = s_l * exp(m_l - M), total = butterfly sum of the t_l (64-groups, then groups
+ * left to right), lse = M + log(total).
+ * And the k largest logits (value desc, index asc). */
 void orc_logsoftmax_topk(const float* x, int64_t ld, int64_t R, int64_t V, int k, float* top_val, int32_t* top_idx,
                          float* lse) {
-    const int64_t nb = (V + 15) / 16;
 #pragma omp parallel for
     for (int64_t r = 0; r < R; ++r) {
         const float* xr = x + r * ld;
-        float* parts = (float*)malloc(sizeof(float) * 2 * nb);
-        for (int64_t b = 0; b < nb; ++b) block_part(xr, b, V, parts + 2 * b, parts + 2 * b + 1);
-        lse[r] = lse_from_parts(parts, nb);
-        free(parts);
+        float pm[256], ps[256];
+        for (int l = 0; l < 256; ++l) { pm[l] = -INFINITY; ps[l] = 0.0f; }
+        int64_t nch = (V + 3) / 4;
+        for (int64_t c0 = 0; c0 < nch; c0 += 1024) {          /* one group per partial and iteration */
+            for (int l = 0; l < 256 && c0 + l < nch; ++l) {
+                float e[16];
+                for (int u = 0; u < 4; ++u)
+                    for (int q = 0; q < 4; ++q) {
+                        int64_t idx = 4 * (c0 + l + 256 * u) + q;
+                        e[4 * u + q] = idx < V ? xr[idx] : -INFINITY;
+                    }
+                float mn = pm[l];
+                for (int i = 0; i < 16; ++i) mn = fmaxf(mn, e[i]);
+                float sacc = ps[l] * orc_exp(pm[l] - mn);
+                for (int i = 0; i < 16; ++i) sacc = sacc + orc_exp(e[i] - mn);
+                ps[l] = sacc;
+                pm[l] = mn;
+            }
+        }
+        float M = pm[0];
+        for (int l = 1; l < 256; ++l) if (pm[l] > M) M = pm[l];
+        float p[256];
+        for (int l = 0; l < 256; ++l) p[l] = ps[l] * orc_exp(pm[l] - M);
+        lse[r] = M + orc_log(sum_butterfly(p, 256));
         for (int j = 0; j < k; ++j) { top_val[r * k + j] = -INFINITY; top_idx[r * k + j] = -1; }
         for (int64_t v = 0; v < V; ++v) {
             float xv = xr[v];

@@ -149,15 +149,6 @@ def logsoftmax_topk(x, k):
     return val, idx, lse
 
 
-def lse_parts(x):
-    """the (m_b, s_b) pairs of the canonical log-sum-exp: [R, ceil(V / 16), 2]"""
-    x, px = _f(x)
-    R, V = x.shape
-    parts = np.empty((R, (V + 15) // 16, 2), dtype=np.float32)
-    lib().orc_lse_parts(px, _i64(V), _i64(R), _i64(V), parts.ctypes.data_as(_f32p))
-    return parts
-
-
 def sample_rows(x, temperature, seed, step, sent):
     x, px = _f(x)
     sent, ps = _i(sent)

@@ -174,37 +174,6 @@ def test_logsoftmax_topk_bit_exact(K, V, k):
     assert np.allclose(wl, ref, rtol=1e-6, atol=1e-6)
 
 
-@pytest.mark.parametrize('M,N,Kd', [(70, 1000, 64), (300, 2048, 256), (129, 33001, 32), (5000, 4100, 256), (3, 20, 8)])
-def test_vocab_gemm_with_lse_partials_and_finish(K, M, N, Kd):
-    """The vocabulary GEMM's epilogue emits the same partials as the stand-alone pass over its own logits, the
-    logits equal the plain GEMM's, and the finishing kernel gives the oracle's lse / top-k (all bit for bit)."""
-    r = rs(M + N)
-    A = r.standard_normal((M, Kd)).astype(np.float32)
-    ldw = (N + 3) // 4 * 4
-    W = np.zeros((Kd, ldw), np.float32)
-    W[:, :N] = r.standard_normal((Kd, N)).astype(np.float32) / np.sqrt(Kd)
-    b = r.standard_normal(N).astype(np.float32)
-    Wd = dev(W)
-    logits = torch.full((M, ldw), 3.0, dtype=torch.float32, device='cuda')
-    plain = torch.empty((M, ldw), dtype=torch.float32, device='cuda')
-    parts = torch.full((M, K.n_blocks(N), 2), 9.0, dtype=torch.float32, device='cuda')
-    K.gemm_vocab_lse(dev(A), Wd[:, :N], dev(b), logits, parts, M, N)
-    K.gemm(dev(A), Wd[:, :N], dev(b), plain, M)
-    lg = logits[:, :N].cpu().numpy()
-    assert np.array_equal(lg, plain[:, :N].cpu().numpy())
-    assert np.array_equal(lg, C.gemm(A, W[:, :N], b))
-    assert np.array_equal(parts.cpu().numpy(), C.lse_parts(lg))
-    for k in (1, 4):
-        tv = torch.empty((M, k), dtype=torch.float32, device='cuda')
-        ti = torch.empty((M, k), dtype=torch.int32, device='cuda')
-        lse = torch.empty(M, dtype=torch.float32, device='cuda')
-        K.topk_from_parts(logits, parts, M, N, k, tv, ti, lse)
-        wv, wi, wl = C.logsoftmax_topk(lg, k)
-        assert np.array_equal(ti.cpu().numpy(), wi) and np.array_equal(tv.cpu().numpy(), wv)
-        assert np.array_equal(lse.cpu().numpy(), wl)
-    assert np.array_equal(ti.cpu().numpy()[:, 0], lg.argmax(1))                      # k = 1 is the arg-max
-
-
 def test_logsoftmax_topk_unaligned_rows(K):
     r = rs(77)
     V, R, k = 1001, 6, 4

@@ -35,9 +35,6 @@ _PROTOS = {
     'tst_argmax_rows_f32': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_vp], c_int),
     'tst_sample_rows_f32': ([c_vp, c_i64, c_i64, c_i64, c_f32, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp, c_vp], c_int),
     'tst_logsoftmax_topk_f32': ([c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp], c_int),
-    'tst_gemm_vocab_lse_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
-    'tst_topk_from_parts_f32': ([c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp], c_int),
-    'tst_topk_from_parts_bf16': ([c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp], c_int),
     'tst_layernorm_f32_bf16': ([c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_add_rows_f32': ([c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_gemm_mfma_bf16': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp],

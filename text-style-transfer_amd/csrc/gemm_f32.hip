@@ -20,12 +20,11 @@ constexpr int BK = 16, GROUP_M = 16;
 // WTM x WTN = MFMA tiles (32 x 32) per wave: the workgroup tile is (64 * WTM) x (64 * WTN).
 // 2 x 4 (128 x 256: fewest LDS reads and staged bytes per MFMA) for wide outputs, 2 x 2 (128 x 128) for
 // large problems, 1 x 1 (64 x 64) when the 128-tiling would leave CUs without work.
-template <int WTM, int WTN, bool FULL_K, bool HAS_RES, bool RELU, bool LSE>
+template <int WTM, int WTN, bool FULL_K, bool HAS_RES, bool RELU>
 __global__ __launch_bounds__(256, (WTN == 4 ? 2 : 1)) void gemm_f32_kernel(const float* __restrict__ A, int64_t lda,
                                                        const float* __restrict__ W, int64_t ldw,
                                                        const float* __restrict__ bias, const float* res, int64_t ldr,
-                                                       float* C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n,
-                                                       float* __restrict__ parts, int nb) {
+                                                       float* C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
     constexpr int BM = 64 * WTM, BN = 64 * WTN, LDA = BM + 4, LDB = BN + 4;
     constexpr int NLA = WTM, NLB = WTN;  // float4 loads per thread: BM * BK / 4 / 256 and BN * BK / 4 / 256
     __shared__ __attribute__((aligned(16))) float As[3][BK][LDA];
@@ -162,29 +161,6 @@ __global__ __launch_bounds__(256, (WTN == 4 ? 2 : 1)) void gemm_f32_kernel(const
     }
 #undef TST_READ_OPERANDS
 
-    // Log-sum-exp partials of the output rows (vocabulary projection): per row and block of 16 columns the pair
-    // (m, s) = (max, sum of exp(x - m) by the xor-butterfly 1, 2, 4, 8).  A 32 x 32 accumulator tile holds, per
-    // register, 32 consecutive columns of one row in lanes 0..31 and of another row in lanes 32..63, so a block
-    // is one DPP row of 16 lanes: no LDS, no shuffles through the LDS crossbar.
-    if (LSE) {
-#pragma unroll
-        for (int i = 0; i < WTM; ++i)
-#pragma unroll
-            for (int j = 0; j < WTN; ++j) {
-                const int col = n0 + wn * 32 * WTN + j * 32 + (lane & 31);
-                const int row0 = m0 + wm * 32 * WTM + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row0 + (r & 3) + 8 * (r >> 2);
-                    const float x = col < N ? acc[i][j][r] : -INFINITY;
-                    const float m = group16_max(x);
-                    const float sum = group16_sum_asc(d_exp_le0(x - m));
-                    if ((lane & 15) == 0 && row < M && col < N)
-                        *reinterpret_cast<float2*>(parts + ((int64_t)row * nb + (col >> 4)) * 2) = make_float2(m, sum);
-                }
-            }
-    }
-
     // epilogue: lane owns column col of 16 rows per 32 x 32 tile (rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5));
     // tiles that lie fully inside the matrix take the unguarded path
     const bool full_tile = m0 + BM <= M && n0 + BN <= N;
@@ -235,20 +211,13 @@ __global__ __launch_bounds__(256, (WTN == 4 ? 2 : 1)) void gemm_f32_kernel(const
 
 template <int WTM, int WTN>
 void launch_gemm(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res, int64_t ldr,
-                 float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st, float* parts = nullptr) {
+                 float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st) {
     constexpr int BTM = 64 * WTM, BTN = 64 * WTN;
     const int64_t tiles_m = (M + BTM - 1) / BTM, tiles_n = (N + BTN - 1) / BTN;
     const dim3 grid((unsigned)(tiles_m * tiles_n));
-    const int nb = (int)((N + 15) / 16);
-#define TST_GEMM_LAUNCH_(FK, HR, RL, LS)                                                                               \
-    hipLaunchKernelGGL((gemm_f32_kernel<WTM, WTN, FK, HR, RL, LS>), grid, dim3(256), 0, st, A, lda, Wt, ldw, bias, res, ldr, C, \
-                       ldc, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n, parts, nb)
-#define TST_GEMM_LAUNCH(FK, HR, RL) TST_GEMM_LAUNCH_(FK, HR, RL, false)
-    if (parts != nullptr) {  // vocabulary projection with log-sum-exp partials: no activation, no residual
-        if (K % BK == 0) TST_GEMM_LAUNCH_(true, false, false, true);
-        else TST_GEMM_LAUNCH_(false, false, false, true);
-        return;
-    }
+#define TST_GEMM_LAUNCH(FK, HR, RL)                                                                                    \
+    hipLaunchKernelGGL((gemm_f32_kernel<WTM, WTN, FK, HR, RL>), grid, dim3(256), 0, st, A, lda, Wt, ldw, bias, res, ldr, C, ldc, \
+                       (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n)
     const int variant = (K % BK == 0 ? 4 : 0) | (res != nullptr ? 2 : 0) | (act == 1 ? 1 : 0);
     switch (variant) {
         case 0: TST_GEMM_LAUNCH(false, false, false); break;
@@ -261,7 +230,6 @@ void launch_gemm(const float* A, int64_t lda, const float* Wt, int64_t ldw, cons
         default: TST_GEMM_LAUNCH(true, true, true); break;
     }
 #undef TST_GEMM_LAUNCH
-#undef TST_GEMM_LAUNCH_
 }
 
 }  // namespace
@@ -288,28 +256,4 @@ extern "C" int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, i
     else
         launch_gemm<1, 1>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
     return tst_after_launch("tst_gemm_mfma_f32");
-}
-
-extern "C" int tst_gemm_vocab_lse_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias,
-                                      float* logits, int64_t ldc, float* parts, int64_t M, int64_t N, int64_t K,
-                                      void* stream) {
-    TST_REQUIRE(A && Wt && logits && parts, TST_ERR_ARG, "tst_gemm_vocab_lse_f32: null pointer");
-    TST_REQUIRE(M >= 0 && N > 0 && K >= 4, TST_ERR_ARG, "tst_gemm_vocab_lse_f32: bad sizes M=%lld N=%lld K=%lld", (long long)M,
-                (long long)N, (long long)K);
-    TST_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= K && ldw >= N && ldc >= N, TST_ERR_ARG,
-                "tst_gemm_vocab_lse_f32: K, lda, ldw must be multiples of 4 and lda >= K, ldw >= N, ldc >= N");
-    TST_REQUIRE(tst_aligned16(A) && tst_aligned16(Wt) && (reinterpret_cast<uintptr_t>(parts) & 7u) == 0, TST_ERR_ARG,
-                "tst_gemm_vocab_lse_f32: A and Wt must be 16-byte aligned, parts 8-byte aligned");
-    TST_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_vocab_lse_f32: size");
-    if (M == 0) return TST_OK;
-    TST_REQUIRE(((M + 63) / 64) * ((N + 63) / 64) < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_vocab_lse_f32: grid too large");
-    const int64_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    hipStream_t st = (hipStream_t)stream;
-    if (big_tiles >= 4096 && N >= 2048)
-        launch_gemm<2, 4>(A, lda, Wt, ldw, bias, nullptr, 0, logits, ldc, M, N, K, 0, st, parts);
-    else if (big_tiles >= 512)
-        launch_gemm<2, 2>(A, lda, Wt, ldw, bias, nullptr, 0, logits, ldc, M, N, K, 0, st, parts);
-    else
-        launch_gemm<1, 1>(A, lda, Wt, ldw, bias, nullptr, 0, logits, ldc, M, N, K, 0, st, parts);
-    return tst_after_launch("tst_gemm_vocab_lse_f32");
 }

@@ -119,217 +119,154 @@ __global__ __launch_bounds__(256) void sample_rows_kernel(const T* __restrict__ 
     if (threadIdx.x == 0) tok[blockIdx.x] = bi == INT_MAX ? 0 : bi;
 }
 
-// ---- log-sum-exp + top-k --------------------------------------------------------------------------------
-// Canonical log-sum-exp of a row (the same definition whichever kernel produces the partials):
-//   blocks of 16 consecutive elements (elements at or beyond V count as -inf): m_b = max,
-//   s_b = sum of exp(x - m_b) by the xor-butterfly 1, 2, 4, 8;  64 accumulators, accumulator q takes the blocks
-//   q, q + 64, ... in order:  m' = max(m_q, m_b);  a_q = a_q * exp(m_q - m') + s_b * exp(m_b - m');  m_q = m';
-//   M = max_q m_q;  total = xor-butterfly (32..1) over q of a_q * exp(m_q - M);  lse = M + log(total).
-// logsoftmax_topk_kernel computes it in one pass over the logits.  Alternatively the (m_b, s_b) pairs ("parts",
-// [row][ceil(V / 16)][2]) come from the epilogue of the vocabulary GEMM and topk_from_parts_kernel finishes them.
+constexpr int CAND_CAP = 1024;  // LDS candidate list of the top-k filter
 
-// sum of the EPC exponentials of a lane's chunk by the first butterfly levels (offsets 1, 2 and, for 8 elements, 4)
-__device__ __forceinline__ float chunk_sum_asc(const float (&e)[4]) { return (e[0] + e[1]) + (e[2] + e[3]); }
-__device__ __forceinline__ float chunk_sum_asc(const float (&e)[8]) {
-    return ((e[0] + e[1]) + (e[2] + e[3])) + ((e[4] + e[5]) + (e[6] + e[7]));
+// exp for arguments <= 0.  fp32 logits: the fixed polynomial (bit-identical on host and device).  bf16 logits
+// carry 8 significant bits and are checked against a tolerance, and their rows hold twice the elements per
+// byte, so the pass is bound by the exponentials: there the hardware's exp2 (v_exp_f32, ~1 ulp) is used.
+template <bool FAST>
+__device__ __forceinline__ float exp_le0(float x) {
+    if (FAST) return x > -100.0f ? __builtin_amdgcn_exp2f(x * 1.44269504088896341f) : 0.0f;   // false for NaN too
+    return d_exp_le0(x);
+}
+
+// online log-sum-exp update with a group of 4 chunks (ascending index order within the group)
+template <int EPC>
+__device__ __forceinline__ void lse_consume(const float (&vv)[4][EPC], float& m, float& sacc) {
+    constexpr bool FAST = EPC == 8;
+    float mn = m;
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < EPC; ++q) mn = fmaxf(mn, vv[u][q]);
+    sacc = sacc * exp_le0<FAST>(m - mn);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int q = 0; q < EPC; ++q) sacc = sacc + exp_le0<FAST>(vv[u][q] - mn);
+    m = mn;
 }
 
 __device__ __forceinline__ float elem_at(const float* xr, int i) { return xr[i]; }
 __device__ __forceinline__ float elem_at(const __bf16* xr, int i) { return (float)xr[i]; }
 
-// Stand-alone kernel: ONE pass over the logits.  A row is handled by TPR = 64 * LPB threads, LPB = lanes per
-// 16-element block (4 for fp32, 2 for bf16: one 16-byte chunk per lane), i.e. by 4 or 2 waves; a 256-thread
-// workgroup takes 256 / TPR rows.  Thread u of a row owns the chunks u, u + TPR, ..., so the LPB lanes of a
-// group hold the blocks g, g + 64, ... of accumulator g = u / LPB: they combine their chunks by DPP inside the
-// quad and all keep the accumulator's online state (m, a).  Four chunks are loaded per iteration to keep
-// enough bytes in flight.  The row's first wave then finishes: lse from the 64 accumulators, tau = the K-th
-// largest accumulator maximum; the threads whose maximum reaches tau re-read their own chunks and push the
-// elements >= tau to an LDS list, from which the first wave picks the K largest (value desc, index asc).
-// Three workgroup barriers in all.
+// One workgroup per row, ONE pass over the row: each logit is read from HBM once and only a few registers
+// are live, so occupancy is high and the loads overlap the arithmetic.  Thread t owns the 16-byte chunks
+// t, t + 256, ... and consumes them four at a time (values x_i in ascending index order) into an online
+// log-sum-exp state:  m' = max(m, x_i);  s = s * exp(m - m') + sum_i exp(x_i - m');  m = m'.
+// The 256 states go to LDS and the FIRST WAVE finishes alone (no further workgroup-wide reductions):
+// M = max of the 256 m, total = butterfly sum of s * exp(m - M) per group of 64 states, groups left to right,
+// lse = M + log(total).
+// Top K: m is also the thread's largest element.  tau = the K-th largest of the 256 thread maxima; at least K
+// elements are >= tau and they can only sit in threads whose own maximum is >= tau, so only the chunks of those
+// (about K) threads are re-read - by the whole workgroup, one chunk per lane - and their elements >= tau pushed
+// to an LDS list, from which the first wave picks the K
+// largest (value desc, index asc) by K wave arg-max rounds.  If the list overflows (many equal values) the
+// first wave's K rounds run over the whole row instead.  Three workgroup barriers in all.
 template <typename T, int K, bool VEC>
-__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const T* __restrict__ x, int64_t ld, int V, int64_t R,
+__global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const T* __restrict__ x, int64_t ld, int V,
                                                               float* __restrict__ top_val, int32_t* __restrict__ top_idx,
                                                               float* __restrict__ lse) {
-    constexpr int EPC = Elem<T>::EPC, LPB = 16 / EPC, TPR = 64 * LPB, RPB = 256 / TPR, CAP = 1024 / RPB;
-    __shared__ float acc_m[RPB][64], acc_a[RPB][64], tau_s[RPB];
-    __shared__ float cand_v[RPB][CAP];
-    __shared__ int cand_i[RPB][CAP];
-    __shared__ int cand_n[RPB];
-    const int t = threadIdx.x, u = t % TPR, rl = t / TPR, lane = t & 63;
-    const bool first_wave = u < 64;
-    int64_t r = (int64_t)blockIdx.x * RPB + rl;
-    const bool row_ok = r < R;
-    if (!row_ok) r = R - 1;                      // a surplus half-workgroup redoes the last row and writes nothing
+    constexpr int EPC = Elem<T>::EPC;
+    __shared__ float st_m[256], st_s[256];
+    __shared__ float tau_s;
+    __shared__ int hot[256], n_hot;   // threads whose maximum reaches tau
+    __shared__ float cand_v[CAND_CAP];
+    __shared__ int cand_i[CAND_CAP];
+    __shared__ int cand_n;
+    const int t = threadIdx.x;
+    const int64_t r = blockIdx.x;
     const T* xr = x + r * ld;
-    const int nb = (V + 15) >> 4, nch = nb * LPB;  // whole blocks: a chunk past the row reads as -inf
-    float mq = -INFINITY, aq = 0.0f;
-    auto consume = [&](const float (&e0)[EPC]) {   // one chunk of every lane of the group = one block
-        float e[EPC];
-        float m = e0[0];
-#pragma unroll
-        for (int q = 1; q < EPC; ++q) m = fmaxf(m, e0[q]);
-        m = fmaxf(m, dpp_row<DPP_XOR1>(m));
-        if (LPB == 4) m = fmaxf(m, dpp_row<DPP_XOR2>(m));
-#pragma unroll
-        for (int q = 0; q < EPC; ++q) e[q] = d_exp_le0(e0[q] - m);
-        float sb = chunk_sum_asc(e);
-        sb = sb + dpp_row<DPP_XOR1>(sb);
-        if (LPB == 4) sb = sb + dpp_row<DPP_XOR2>(sb);
-        const float mn = fmaxf(mq, m);
-        aq = aq * d_exp_le0(mq - mn) + sb * d_exp_le0(m - mn);
-        mq = mn;
-    };
-    int c0 = u;
-    if (VEC) {  // blocks that lie fully inside the row (the same bound for all lanes of a group, which run the
-                // DPP steps together): unguarded 16-byte loads, four in flight
-        const int nfull = (V >> 4) * LPB;
-        for (; c0 + 3 * TPR < nfull; c0 += 4 * TPR) {
+    const int nch = (V + EPC - 1) / EPC;
+    float m = -INFINITY, sacc = 0.0f;
+    // a chunk beyond the row reads as -inf and contributes exp(-inf) = 0
+    int c0 = t;
+    if (VEC) {  // groups that lie fully inside the row: unguarded 16-byte loads
+        const int nfull = V / EPC;
+        for (; c0 + 768 < nfull; c0 += 1024) {
             float vv[4][EPC];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) load_chunk(xr, c0 + TPR * i, INT_MAX, true, vv[i]);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) consume(vv[i]);
+            for (int u = 0; u < 4; ++u) load_chunk(xr, c0 + 256 * u, INT_MAX, true, vv[u]);
+            lse_consume<EPC>(vv, m, sacc);
         }
     }
-    for (; c0 < nch; c0 += TPR) {  // ragged end of the row (and rows that are not 16-byte aligned)
-        float vv[EPC];
-        load_chunk(xr, c0, V, VEC, vv);
-        consume(vv);
+    for (; c0 < nch; c0 += 1024) {  // ragged end of the row (and rows that are not 16-byte aligned)
+        float vv[4][EPC];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) load_chunk(xr, c0 + 256 * u, V, VEC, vv[u]);
+        lse_consume<EPC>(vv, m, sacc);
     }
-    if ((u & (LPB - 1)) == 0) { acc_m[rl][u / LPB] = mq; acc_a[rl][u / LPB] = aq; }
+    st_m[t] = m;
+    st_s[t] = sacc;
     __syncthreads();
-    if (first_wave) {
-        const float m_l = acc_m[rl][lane], a_l = acc_a[rl][lane];
-        const float M = wave_max(m_l);
-        const float total = wave_sum_butterfly(a_l * d_exp_le0(m_l - M));
-        if (lane == 0 && row_ok) lse[r] = M + d_log(total);
-        float tau = -INFINITY, cand = m_l;   // K-th largest accumulator maximum (ties: lower accumulator first)
+    if (t < 64) {
+        float mg[4], sg[4], m0[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { mg[g] = st_m[t + 64 * g]; sg[g] = st_s[t + 64 * g]; m0[g] = mg[g]; }
+        const float M = wave_max(fmaxf(fmaxf(mg[0], mg[1]), fmaxf(mg[2], mg[3])));
+        float part[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) part[g] = wave_sum_butterfly(sg[g] * d_exp_le0(mg[g] - M));
+        if (t == 0) lse[r] = M + d_log(((part[0] + part[1]) + part[2]) + part[3]);
+        // K-th largest thread maximum (ties between threads: lower thread first)
+        float tau = -INFINITY;
         for (int o = 0; o < K; ++o) {
-            float v = cand;
-            int id = lane;
+            float v = mg[0];
+            int id = t;
+#pragma unroll
+            for (int g = 1; g < 4; ++g)
+                if (mg[g] > v) { v = mg[g]; id = t + 64 * g; }
+            const int mine = id;
             wave_argmax(v, id);
             tau = v;
-            if (id == lane) cand = -INFINITY;
-        }
-        if (lane == 0) { tau_s[rl] = tau; cand_n[rl] = 0; }
-    }
-    __syncthreads();
-    const float tau = tau_s[rl];
-    if (mq >= tau) {  // the lanes of about K groups
-        for (int c = u; c < nch; c += TPR) {
-            float e[EPC];
-            load_chunk(xr, c, V, VEC, e);
+            if (id == mine) {
 #pragma unroll
-            for (int q = 0; q < EPC; ++q)
-                if (e[q] >= tau && EPC * c + q < V) {
-                    const int at = atomicAdd(&cand_n[rl], 1);
-                    if (at < CAP) { cand_v[rl][at] = e[q]; cand_i[rl][at] = EPC * c + q; }
-                }
+                for (int g = 0; g < 4; ++g)
+                    if (id == t + 64 * g) mg[g] = -INFINITY;
+            }
         }
+        int nh = 0;   // list of the (about K) threads whose maximum reaches tau
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const bool is_hot = m0[g] >= tau;
+            const unsigned long long bal = __ballot(is_hot);
+            if (is_hot) hot[nh + __popcll(bal & ((1ull << t) - 1ull))] = t + 64 * g;
+            nh += __popcll(bal);
+        }
+        if (t == 0) { tau_s = tau; cand_n = 0; n_hot = nh; }
     }
     __syncthreads();
-    if (!first_wave) return;
-    const int ncand = cand_n[rl];
-    if (ncand <= CAP) {
-        for (int o = 0; o < K; ++o) {
-            float bv = -INFINITY;
-            int bi = INT_MAX, be = -1;
-            for (int e = lane; e < ncand; e += 64)
-                if (better(cand_v[rl][e], cand_i[rl][e], bv, bi)) { bv = cand_v[rl][e]; bi = cand_i[rl][e]; be = e; }
-            const int mine = bi;
-            wave_argmax(bv, bi);
-            if (be >= 0 && bi == mine) { cand_v[rl][be] = -INFINITY; cand_i[rl][be] = INT_MAX; }
-            if (lane == 0 && row_ok) { top_val[r * K + o] = bv; top_idx[r * K + o] = bi == INT_MAX ? -1 : bi; }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        }
-    } else {
-        float lastv = INFINITY;
-        int lasti = -1;
-        for (int o = 0; o < K; ++o) {
-            float bv = -INFINITY;
-            int bi = INT_MAX;
-            for (int id = lane; id < V; id += 64) {
-                const float e = elem_at(xr, id);
-                const bool after = e < lastv || (e == lastv && id > lasti);
-                if (after && better(e, id, bv, bi)) { bv = e; bi = id; }
+    // the whole workgroup re-reads the chunks of the hot threads (chunk h + 256 i of thread h), one chunk per
+    // work item, so that the loads are spread over all lanes instead of running serially in K threads
+    const float tau = tau_s;
+    const int ipt = (nch + 255) >> 8;   // chunks per thread
+    const int items = n_hot * ipt;
+    for (int it = t; it < items; it += 256) {
+        const int c = hot[it / ipt] + 256 * (it % ipt);
+        if (c >= nch) continue;
+        float e[EPC];
+        load_chunk(xr, c, V, VEC, e);
+#pragma unroll
+        for (int q = 0; q < EPC; ++q)
+            if (e[q] >= tau && EPC * c + q < V) {
+                const int at = atomicAdd(&cand_n, 1);
+                if (at < CAND_CAP) { cand_v[at] = e[q]; cand_i[at] = EPC * c + q; }
             }
-            wave_argmax(bv, bi);
-            lastv = bv; lasti = bi;
-            if (lane == 0 && row_ok) { top_val[r * K + o] = bv; top_idx[r * K + o] = bi == INT_MAX ? -1 : bi; }
-        }
     }
-}
-
-constexpr int CAND_CAP = 256;  // per-wave LDS candidate list of the top-k filter
-
-// One WAVE per row (4 rows per workgroup, no workgroup barriers).  Lane q is accumulator q of the canonical
-// log-sum-exp.  Top K: the lane's running maximum is its largest element; tau = the K-th largest of the 64 lane
-// maxima; at least K elements are >= tau and they sit in blocks with m_b >= tau of lanes whose maximum is >= tau,
-// so only those few blocks of logits are read back (16 elements each) and their elements >= tau go to an LDS
-// list, from which K rounds of wave arg-max (value desc, index asc) pick the result.  If the list overflows (very
-// many equal values) the K rounds scan the whole row instead.
-template <typename T, int K>
-__global__ __launch_bounds__(256) void topk_from_parts_kernel(const T* __restrict__ x, int64_t ld, int V,
-                                                              const float* __restrict__ parts, int nb, int64_t R,
-                                                              float* __restrict__ top_val, int32_t* __restrict__ top_idx,
-                                                              float* __restrict__ lse) {
-    __shared__ float cand_v[4][CAND_CAP];
-    __shared__ int cand_i[4][CAND_CAP];
-    __shared__ int cand_n[4];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * 4 + w;
-    if (r >= R) return;
-    const T* xr = x + r * ld;
-    const float2* pr = reinterpret_cast<const float2*>(parts) + r * nb;
-    if (lane == 0) cand_n[w] = 0;
-    float mq = -INFINITY, aq = 0.0f;
-    for (int b = lane; b < nb; b += 64) {
-        const float2 p = pr[b];
-        const float mn = fmaxf(mq, p.x);
-        aq = aq * d_exp_le0(mq - mn) + p.y * d_exp_le0(p.x - mn);
-        mq = mn;
-    }
-    const float M = wave_max(mq);
-    const float total = wave_sum_butterfly(aq * d_exp_le0(mq - M));
-    if (lane == 0) lse[r] = M + d_log(total);
-    // K-th largest lane maximum (ties between lanes: lower lane first)
-    float tau = -INFINITY, cand = mq;
-    for (int o = 0; o < K; ++o) {
-        float v = cand;
-        int id = lane;
-        wave_argmax(v, id);
-        tau = v;
-        if (id == lane) cand = -INFINITY;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // cand_n[w] = 0 is visible to the wave's atomics
-    if (mq >= tau) {  // about K lanes
-        for (int b = lane; b < nb; b += 64) {
-            if (pr[b].x < tau) continue;
-#pragma unroll 4
-            for (int q = 0; q < 16; ++q) {
-                const int id = 16 * b + q;
-                if (id >= V) break;
-                const float e = elem_at(xr, id);
-                if (e >= tau) {
-                    const int at = atomicAdd(&cand_n[w], 1);
-                    if (at < CAND_CAP) { cand_v[w][at] = e; cand_i[w][at] = id; }
-                }
-            }
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    const int ncand = cand_n[w];
+    __syncthreads();
+    if (t >= 64) return;
+    const int ncand = cand_n;
     if (ncand <= CAND_CAP) {
         for (int o = 0; o < K; ++o) {
             float bv = -INFINITY;
             int bi = INT_MAX, be = -1;
-            for (int e = lane; e < ncand; e += 64)
-                if (better(cand_v[w][e], cand_i[w][e], bv, bi)) { bv = cand_v[w][e]; bi = cand_i[w][e]; be = e; }
+            for (int e = t; e < ncand; e += 64)
+                if (better(cand_v[e], cand_i[e], bv, bi)) { bv = cand_v[e]; bi = cand_i[e]; be = e; }
             const int mine = bi;
             wave_argmax(bv, bi);
-            if (be >= 0 && bi == mine) { cand_v[w][be] = -INFINITY; cand_i[w][be] = INT_MAX; }
-            if (lane == 0) { top_val[r * K + o] = bv; top_idx[r * K + o] = bi == INT_MAX ? -1 : bi; }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            if (be >= 0 && bi == mine) { cand_v[be] = -INFINITY; cand_i[be] = INT_MAX; }
+            if (t == 0) { top_val[r * K + o] = bv; top_idx[r * K + o] = bi == INT_MAX ? -1 : bi; }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");   // the removal is seen by the wave's next round
         }
     } else {
         float lastv = INFINITY;
@@ -337,14 +274,14 @@ __global__ __launch_bounds__(256) void topk_from_parts_kernel(const T* __restric
         for (int o = 0; o < K; ++o) {
             float bv = -INFINITY;
             int bi = INT_MAX;
-            for (int id = lane; id < V; id += 64) {
+            for (int id = t; id < V; id += 64) {
                 const float e = elem_at(xr, id);
                 const bool after = e < lastv || (e == lastv && id > lasti);
                 if (after && better(e, id, bv, bi)) { bv = e; bi = id; }
             }
             wave_argmax(bv, bi);
             lastv = bv; lasti = bi;
-            if (lane == 0) { top_val[r * K + o] = bv; top_idx[r * K + o] = bi == INT_MAX ? -1 : bi; }
+            if (t == 0) { top_val[r * K + o] = bv; top_idx[r * K + o] = bi == INT_MAX ? -1 : bi; }
         }
     }
 }
@@ -507,43 +444,12 @@ template <typename T>
 inline int row_vec_ok(const T* x, int64_t ld) { return (tst_aligned16(x) && ld % Elem<T>::EPC == 0) ? 1 : 0; }
 
 template <typename T, int K>
-int launch_finish(const T* logits, int64_t ld, int64_t R, int64_t V, const float* parts, float* tv, int32_t* ti, float* lse,
-                  hipStream_t st, const char* name) {
-    hipLaunchKernelGGL((topk_from_parts_kernel<T, K>), dim3(blocks_for(R, 4)), dim3(256), 0, st, logits, ld, (int)V, parts,
-                       (int)((V + 15) / 16), R, tv, ti, lse);
-    return tst_after_launch(name);
-}
-
-template <typename T>
-int finish_entry(const T* logits, int64_t ld, int64_t R, int64_t V, int64_t k, const float* parts, float* top_val,
-                 int32_t* top_idx, float* lse, void* stream, const char* name) {
-    TST_REQUIRE(logits && parts && top_val && top_idx && lse, TST_ERR_ARG, "%s: null pointer", name);
-    TST_REQUIRE(R >= 0 && V > 0 && ld >= V && V < (1ll << 30) && R < (1ll << 31), TST_ERR_ARG, "%s: bad sizes", name);
-    TST_REQUIRE(k >= 1 && k <= 8 && k <= V, TST_ERR_UNSUPPORTED, "%s: need 1 <= k <= min(8, V)", name);
-    TST_REQUIRE((reinterpret_cast<uintptr_t>(parts) & 7u) == 0, TST_ERR_ARG, "%s: parts must be 8-byte aligned", name);
-    if (R == 0) return TST_OK;
-    hipStream_t st = (hipStream_t)stream;
-    switch (k) {
-        case 1: return launch_finish<T, 1>(logits, ld, R, V, parts, top_val, top_idx, lse, st, name);
-        case 2: return launch_finish<T, 2>(logits, ld, R, V, parts, top_val, top_idx, lse, st, name);
-        case 3: return launch_finish<T, 3>(logits, ld, R, V, parts, top_val, top_idx, lse, st, name);
-        case 4: return launch_finish<T, 4>(logits, ld, R, V, parts, top_val, top_idx, lse, st, name);
-        case 5: return launch_finish<T, 5>(logits, ld, R, V, parts, top_val, top_idx, lse, st, name);
-        case 6: return launch_finish<T, 6>(logits, ld, R, V, parts, top_val, top_idx, lse, st, name);
-        case 7: return launch_finish<T, 7>(logits, ld, R, V, parts, top_val, top_idx, lse, st, name);
-        default: return launch_finish<T, 8>(logits, ld, R, V, parts, top_val, top_idx, lse, st, name);
-    }
-}
-
-template <typename T, int K>
 int launch_topk(const T* logits, int64_t ld, int64_t R, int64_t V, float* tv, int32_t* ti, float* lse, hipStream_t st,
                 const char* name) {
-    constexpr int RPB = 256 / (64 * (16 / Elem<T>::EPC));   // rows per workgroup
-    const dim3 grid(blocks_for(R, RPB));
     if (row_vec_ok(logits, ld))
-        hipLaunchKernelGGL((logsoftmax_topk_kernel<T, K, true>), grid, dim3(256), 0, st, logits, ld, (int)V, R, tv, ti, lse);
+        hipLaunchKernelGGL((logsoftmax_topk_kernel<T, K, true>), dim3((unsigned)R), dim3(256), 0, st, logits, ld, (int)V, tv, ti, lse);
     else
-        hipLaunchKernelGGL((logsoftmax_topk_kernel<T, K, false>), grid, dim3(256), 0, st, logits, ld, (int)V, R, tv, ti, lse);
+        hipLaunchKernelGGL((logsoftmax_topk_kernel<T, K, false>), dim3((unsigned)R), dim3(256), 0, st, logits, ld, (int)V, tv, ti, lse);
     return tst_after_launch(name);
 }
 
@@ -622,17 +528,6 @@ extern "C" int tst_logsoftmax_topk_f32(const float* logits, int64_t ld, int64_t 
 extern "C" int tst_logsoftmax_topk_bf16(const void* logits, int64_t ld, int64_t R, int64_t V, int64_t k, float* top_val,
                                         int32_t* top_idx, float* lse, void* stream) {
     return topk_entry<__bf16>((const __bf16*)logits, ld, R, V, k, top_val, top_idx, lse, stream, "tst_logsoftmax_topk_bf16");
-}
-
-extern "C" int tst_topk_from_parts_f32(const float* logits, int64_t ld, const float* parts, int64_t R, int64_t V, int64_t k,
-                                       float* top_val, int32_t* top_idx, float* lse, void* stream) {
-    return finish_entry<float>(logits, ld, R, V, k, parts, top_val, top_idx, lse, stream, "tst_topk_from_parts_f32");
-}
-
-extern "C" int tst_topk_from_parts_bf16(const void* logits, int64_t ld, const float* parts, int64_t R, int64_t V, int64_t k,
-                                        float* top_val, int32_t* top_idx, float* lse, void* stream) {
-    return finish_entry<__bf16>((const __bf16*)logits, ld, R, V, k, parts, top_val, top_idx, lse, stream,
-                                "tst_topk_from_parts_bf16");
 }
 
 extern "C" int tst_greedy_select(const int32_t* argmax_tok, int64_t n_rows, int32_t eos, int32_t* sel_parent,

@@ -44,33 +44,6 @@ __device__ __forceinline__ float group16_sum_butterfly(float v) {
     return v;
 }
 
-// DPP lane permutations inside aligned rows of 16 lanes (no LDS, no cross-row traffic)
-template <int CTRL>
-__device__ __forceinline__ float dpp_row(float v) {
-    const int i = __builtin_bit_cast(int, v);
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(i, i, CTRL, 0xf, 0xf, false));
-}
-constexpr int DPP_XOR1 = 0xB1;         // quad_perm [1,0,3,2]
-constexpr int DPP_XOR2 = 0x4E;         // quad_perm [2,3,0,1]
-constexpr int DPP_HALF_MIRROR = 0x141; // lane i <-> 7 - i of its group of 8: the other quad
-constexpr int DPP_MIRROR = 0x140;      // lane i <-> 15 - i of its row of 16: the other group of 8
-
-// max over an aligned group of 16 lanes; every lane gets it
-__device__ __forceinline__ float group16_max(float v) {
-    v = fmaxf(v, dpp_row<DPP_XOR1>(v));
-    v = fmaxf(v, dpp_row<DPP_XOR2>(v));
-    v = fmaxf(v, dpp_row<DPP_HALF_MIRROR>(v));   // quads are uniform by now: the mirror lane holds the other quad's value
-    return fmaxf(v, dpp_row<DPP_MIRROR>(v));
-}
-
-// sum over an aligned group of 16 lanes by the xor-butterfly with offsets 1, 2, 4, 8 (in this order)
-__device__ __forceinline__ float group16_sum_asc(float v) {
-    v = v + dpp_row<DPP_XOR1>(v);
-    v = v + dpp_row<DPP_XOR2>(v);
-    v = v + dpp_row<DPP_HALF_MIRROR>(v);
-    return v + dpp_row<DPP_MIRROR>(v);
-}
-
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));

@@ -9,9 +9,7 @@ of the unfinished rows after ``max_len`` steps (``:65-69``) — with all bookkee
 A *session* provides:
   ``V``               vocabulary size
   ``needs_anc``       whether it reads the ancestor table (incremental KV cache)
-  ``step(rows, n_rows, t) -> logits``   fp32 or bf16 GPU tensor [>= n_rows, >= V], unit inner stride
-  ``parts``           (optional) fp32 tensor [>= n_rows, ceil(V / 16), 2] that ``step`` fills with the log-sum-exp
-                      partials of the logits (the vocabulary GEMM's epilogue computes them); None / absent otherwise
+  ``step(rows, n_rows, t) -> logits``   fp32 GPU tensor [>= n_rows, >= V], unit inner stride
   ``reorder(row_parent, n_rows, identity)``  called after each step with the old row of every new row
 Rows: step 0 has one row per sentence (row a = sentence a, per-sentence state in rows 0..B-1 of buffers sized
 for B * beam rows); the first ``reorder`` fans every sentence out to ``beam`` consecutive rows.
@@ -59,9 +57,10 @@ class DecodeLoop:
         self.row_parent = torch.zeros(R, **i32)
         self.n_alive = torch.zeros(1, **i32)
         self.am = torch.zeros(R, **i32)
-        self.top_val = torch.zeros((R, beam), dtype=torch.float32, device=dev)
-        self.top_idx = torch.zeros((R, beam), **i32)
-        self.lse = torch.zeros(R, dtype=torch.float32, device=dev)
+        if beam > 1:
+            self.top_val = torch.zeros((R, beam), dtype=torch.float32, device=dev)
+            self.top_idx = torch.zeros((R, beam), **i32)
+            self.lse = torch.zeros(R, dtype=torch.float32, device=dev)
         self.steps_done = 0
         self.rows_stepped = 0
 
@@ -78,22 +77,14 @@ class DecodeLoop:
             logits = s.step(self.cur, R, t)
             if t < keep_logits:
                 self.kept.append((logits[:R, :s.V].clone(), self.cur.sent[:R].clone(), self.cur.fin[:R].clone()))
-            parts = getattr(s, 'parts', None)
             if k == 1:
-                am = self.am
-                if self.sample is not None:
-                    K.sample_rows(logits, R, s.V, self.sample[0], self.sample[1], t, self.cur.sent, am)
-                elif parts is not None:   # arg-max = top-1 from the partials: reads one 16-logit block per row
-                    K.topk_from_parts(logits, parts, R, s.V, 1, self.top_val, self.top_idx, self.lse)
-                    am = self.top_idx.view(-1)
+                if self.sample is None:
+                    K.argmax_rows(logits, R, s.V, self.am)
                 else:
-                    K.argmax_rows(logits, R, s.V, am)
-                K.greedy_select(am, R, self.eos, self.sel, self.cur)
+                    K.sample_rows(logits, R, s.V, self.sample[0], self.sample[1], t, self.cur.sent, self.am)
+                K.greedy_select(self.am, R, self.eos, self.sel, self.cur)
             else:
-                if parts is not None:
-                    K.topk_from_parts(logits, parts, R, s.V, k, self.top_val, self.top_idx, self.lse)
-                else:
-                    K.logsoftmax_topk(logits, R, s.V, k, self.top_val, self.top_idx, self.lse)
+                K.logsoftmax_topk(logits, R, s.V, k, self.top_val, self.top_idx, self.lse)
                 K.beam_merge(self.cur, self.top_val, self.top_idx, self.lse, n_sent, k, k_in, self.eos, self.sel)
             K.retire_compact(self.cur, self.nxt, self.sel, self.lp, n_sent, k, t, T, self.eos, t == T - 1, self.top_ends,
                              self.out_tok, self.out_len, self.out_score, self.scratch, self.row_parent, self.n_alive)

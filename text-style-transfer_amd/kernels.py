@@ -130,36 +130,10 @@ def sample_rows(logits, n_rows, n_cols, temperature, seed, step, sent, out_tok):
          int(step), _p(sent), _p(out_tok), _stream())
 
 
-def n_blocks(n_cols):
-    """number of 16-element blocks of a row of logits (one (max, sum-exp) pair each)"""
-    return (n_cols + 15) // 16
-
-
 def logsoftmax_topk(logits, n_rows, n_cols, k, top_val, top_idx, lse):
-    """lse and the k largest logits per row, one pass over the logits"""
     _chk(top_val, torch.float32, 'top_val'); _chk(top_idx, torch.int32, 'top_idx'); _chk(lse, torch.float32, 'lse')
-    call('tst_logsoftmax_topk' + _logits_suffix(logits), _p(logits), logits.stride(0), n_rows, n_cols, k, _p(top_val),
-         _p(top_idx), _p(lse), _stream())
-
-
-def gemm_vocab_lse(a, wt, bias, logits, parts, n_rows, n_cols):
-    """logits[:n_rows, :N] = a @ wt + bias and parts[:n_rows] = the (max, sum-exp) pairs of every 16-column block"""
-    for t, nm in ((a, 'a'), (wt, 'wt'), (logits, 'logits'), (bias, 'bias')):
-        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1):
-            raise ValueError('%s must be an fp32 GPU tensor with unit inner stride' % nm)
-    _chk(parts, torch.float32, 'parts')
-    K, N = wt.shape[0], n_cols
-    assert a.shape[1] == K and wt.shape[1] >= N and logits.shape[1] >= N and a.shape[0] >= n_rows and logits.shape[0] >= n_rows
-    assert parts.numel() >= n_rows * n_blocks(N) * 2 and (bias is None or bias.numel() >= N)
-    call('tst_gemm_vocab_lse_f32', _p(a), a.stride(0), _p(wt), wt.stride(0), _p(bias), _p(logits), logits.stride(0), _p(parts),
-         n_rows, N, K, _stream())
-
-
-def topk_from_parts(logits, parts, n_rows, n_cols, k, top_val, top_idx, lse):
-    _chk(top_val, torch.float32, 'top_val'); _chk(top_idx, torch.int32, 'top_idx'); _chk(lse, torch.float32, 'lse')
-    _chk(parts, torch.float32, 'parts')
-    call('tst_topk_from_parts' + _logits_suffix(logits), _p(logits), logits.stride(0), _p(parts), n_rows, n_cols, k, _p(top_val),
-         _p(top_idx), _p(lse), _stream())
+    call('tst_logsoftmax_topk' + _logits_suffix(logits), _p(logits), logits.stride(0), n_rows, n_cols, k, _p(top_val), _p(top_idx), _p(lse),
+         _stream())
 
 
 class RowState:

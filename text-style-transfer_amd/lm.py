@@ -167,8 +167,6 @@ class TransformerLMSession:
         self.logits = torch.empty((R, (lm.V + 7) // 8 * 8), **lo)
         self.scale = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
         self.gemm = K.gemm_bf16 if lm.dtype == 'bf16' else K.gemm
-        from . import transformer
-        self.parts = torch.empty((R, K.n_blocks(lm.V), 2), **f32) if (lm.dtype == 'fp32' and transformer.FUSED_LSE) else None
 
     def reorder(self, row_parent, n_rows, identity):
         pass  # the KV cache is addressed through the ancestor table; nothing moves
@@ -189,16 +187,12 @@ class TransformerLMSession:
             gemm(ff, L['w2'], L['b2'], x, n, res=x)
         K.layernorm(x, W['ln'][0], W['ln'][1], h, n)
         log = lm.event_log
-        if self.parts is not None:
-            vocab = lambda: K.gemm_vocab_lse(h, W['wout'], W['bout'], self.logits, self.parts, n, self.V)
-        else:
-            vocab = lambda: gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
         if log is None:
-            vocab()
+            gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
         else:  # measurement aid: HIP events on the launch stream around the vocabulary projection
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            vocab()
+            gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
             e1.record()
             log.append((e0, e1, 2.0 * n * d * self.V))
         return self.logits

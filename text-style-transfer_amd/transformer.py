@@ -197,12 +197,6 @@ class TransformerDecoder(HipModule):
         return out
 
 
-# Vocabulary projection with the log-sum-exp partials computed in the GEMM epilogue (tst_gemm_vocab_lse_f32 +
-# tst_topk_from_parts_f32) instead of GEMM + one-pass selection.  Same bits; measured slower on MI355X (the
-# exponentials slow the matrix-core-bound GEMM by more than the HBM-bound selection pass saves), so off.
-FUSED_LSE = False
-
-
 class TransformerSession:
     """Per-batch decode state of a ``TransformerDecoder``: cross-attention k|v of the encoder outputs
     (computed once), the self-attention q|k|v cache [layer][position][row slot][3d] and work buffers."""
@@ -236,7 +230,6 @@ class TransformerSession:
         self.a = torch.empty((R, d), **f32)
         self.ff = torch.empty((R, dec.hp.d_ff), **f32)
         self.logits = torch.empty((R, (dec.V + 3) // 4 * 4), **f32)
-        self.parts = torch.empty((R, K.n_blocks(dec.V), 2), **f32) if FUSED_LSE else None
         self.scale = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
 
     def reorder(self, row_parent, n_rows, identity):
@@ -261,16 +254,12 @@ class TransformerSession:
             K.gemm(ff, L['w2'], L['b2'], x, n, res=x)
         K.layernorm(x, W['ln'][0], W['ln'][1], h, n)
         log = dec.event_log
-        if self.parts is not None:
-            vocab = lambda: K.gemm_vocab_lse(h, W['wout'], W['bout'], self.logits, self.parts, n, self.V)
-        else:
-            vocab = lambda: K.gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
         if log is None:
-            vocab()
+            K.gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
         else:  # measurement aid: HIP events on the launch stream around the vocabulary projection
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            vocab()
+            K.gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
             e1.record()
             log.append((e0, e1, 2.0 * n * d * self.V))
         return self.logits
