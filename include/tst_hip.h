@@ -138,7 +138,7 @@ typedef struct tst_rows {
     int32_t* nemit;
 } tst_rows;
 
-/* Beam merge, one sentence per thread.  The sentence has k_in input rows (rows a*k_in .. a*k_in+k_in-1 of
+/* Beam merge, one wave per sentence.  The sentence has k_in input rows (rows a*k_in .. a*k_in+k_in-1 of
  * `cur`, top_val, top_idx [row][k] and lse) and gets k output slots (a*k .. a*k+k-1 of sel_*): every live input
  * beam offers its k best tokens with value score + (top_val - lse), a finished beam offers itself unchanged;
  * the k best offers (ties: lower beam, then lower rank) become the new beams in that order.  At the first

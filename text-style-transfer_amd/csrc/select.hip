@@ -299,51 +299,54 @@ __global__ __launch_bounds__(256) void greedy_select_kernel(const int32_t* __res
     nemit[r] = cur.nemit[r] + 1;
 }
 
-// one thread per sentence; offers are enumerated in (beam, rank) order and picked with a strict compare,
-// which makes ties go to the lower beam, then the lower rank
+// One wave per sentence.  Lane j * k + rk holds the offer (beam j, rank rk); a finished beam has one offer (its
+// own score, rank 0).  k rounds of wave arg-max (value desc, lane asc) pick the new beams: ties go to the lower
+// beam, then the lower rank.  Inactive lanes compete with value -inf and an index past every real lane, so an
+// offer whose score is -inf still wins over "no offer".
 __global__ __launch_bounds__(256) void beam_merge_kernel(tst_rows cur, const float* __restrict__ top_val,
                                                          const int32_t* __restrict__ top_idx,
                                                          const float* __restrict__ lse, int64_t n_sent, int k, int k_in,
                                                          int32_t eos, int32_t* parent, int32_t* tok, float* score,
                                                          int32_t* fin, int32_t* nemit) {
-    const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t a = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (a >= n_sent) return;
     const int64_t base = a * k_in;   // input rows of the sentence
     const int64_t obase = a * k;     // output slots
-    float cv[64];
-    int8_t cj[64];
-    int32_t ct[64];
-    int nc = 0;
-    for (int j = 0; j < k_in; ++j) {
+    const int j = lane / k, rk = lane - j * k;
+    bool active = lane < k_in * k;
+    float val = -INFINITY;
+    int32_t tk = -1;
+    if (active) {
         const int64_t row = base + j;
         if (cur.fin[row]) {
-            cv[nc] = cur.score[row]; cj[nc] = (int8_t)j; ct[nc] = -1; ++nc;
+            active = rk == 0;
+            val = cur.score[row];
         } else {
-            const float sc = cur.score[row], ls = lse[row];
-            for (int rk = 0; rk < k; ++rk) {
-                cv[nc] = sc + (top_val[row * k + rk] - ls);
-                cj[nc] = (int8_t)j; ct[nc] = top_idx[row * k + rk]; ++nc;
-            }
+            val = cur.score[row] + (top_val[row * k + rk] - lse[row]);
+            tk = top_idx[row * k + rk];
         }
     }
-    unsigned long long taken = 0ull;
     for (int o = 0; o < k; ++o) {
-        int best = -1;
-        for (int c = 0; c < nc; ++c)
-            if (!((taken >> c) & 1ull) && (best < 0 || cv[c] > cv[best])) best = c;
+        float v = active ? val : -INFINITY;
+        int id = active ? lane : 1000 + lane;
+        wave_argmax(v, id);
         const int64_t dst = obase + o;
-        if (best < 0) {  // fewer offers than beams: pad with an ended, worthless hypothesis
-            parent[dst] = (int32_t)base; tok[dst] = eos; score[dst] = -INFINITY; fin[dst] = 1; nemit[dst] = 0;
+        if (id >= 1000) {  // fewer offers than beams: pad with an ended, worthless hypothesis
+            if (lane == 0) { parent[dst] = (int32_t)base; tok[dst] = eos; score[dst] = -INFINITY; fin[dst] = 1; nemit[dst] = 0; }
             continue;
         }
-        taken |= 1ull << best;
-        const int64_t prow = base + cj[best];
-        parent[dst] = (int32_t)prow;
-        score[dst] = cv[best];
-        if (ct[best] < 0) {
-            tok[dst] = eos; fin[dst] = 1; nemit[dst] = cur.nemit[prow];
-        } else {
-            tok[dst] = ct[best]; fin[dst] = ct[best] == eos ? 1 : 0; nemit[dst] = cur.nemit[prow] + 1;
+        const int32_t wt = __shfl(tk, id, 64);
+        if (lane == id) active = false;
+        if (lane == 0) {
+            const int64_t prow = base + id / k;
+            parent[dst] = (int32_t)prow;
+            score[dst] = v;
+            if (wt < 0) {
+                tok[dst] = eos; fin[dst] = 1; nemit[dst] = cur.nemit[prow];
+            } else {
+                tok[dst] = wt; fin[dst] = wt == eos ? 1 : 0; nemit[dst] = cur.nemit[prow] + 1;
+            }
         }
     }
 }
@@ -550,7 +553,7 @@ extern "C" int tst_beam_merge(const tst_rows* cur, const float* top_val, const i
     TST_REQUIRE(n_sent >= 0 && k >= 1 && k <= 8 && k_in >= 1 && k_in <= k, TST_ERR_ARG,
                 "tst_beam_merge: need 1 <= k_in <= k <= 8");
     if (n_sent == 0) return TST_OK;
-    hipLaunchKernelGGL(beam_merge_kernel, dim3(blocks_for(n_sent, 256)), dim3(256), 0, (hipStream_t)stream, *cur, top_val,
+    hipLaunchKernelGGL(beam_merge_kernel, dim3(blocks_for(n_sent, 4)), dim3(256), 0, (hipStream_t)stream, *cur, top_val,
                        top_idx, lse, n_sent, (int)k, (int)k_in, eos, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit);
     return tst_after_launch("tst_beam_merge");
 }
