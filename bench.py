@@ -30,6 +30,8 @@ VOCAB = 32000
 MAX_LEN = 50
 OUT_SCALE = 2.0
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak of MI355X
+HBM_PEAK_GBS = 8000.0            # HBM3E peak of MI355X
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r01_vocab_gemm_traffic.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 
 
 def build_model(device, eos_bias):
@@ -41,12 +43,13 @@ def build_model(device, eos_bias):
     return model, vocab
 
 
-def decode_batch(model, vocab, src, beam, alpha):
+def decode_batch(model, vocab, src, beam, alpha, select_log=None):
     """One pass of the hot path: encoder, decode loop; returns device tensors and the loop (for counters)."""
     import tst_amd
     encs, enc_mask = model.encoder(src)
     st = tst_amd.InferenceState({'model': model.decoder, 'inputs': encs, 'enc_mask': enc_mask, 'vocab': vocab,
                                  'max_len': MAX_LEN, 'beam_size': beam, 'length_penalty': alpha})
+    st.select_log = select_log      # HIP events around every log-softmax/top-k launch (None: not timed)
     tok, lens, _ = st.decode_packed()   # device tensors; the per-sentence list of the reference API is not built
     return tok, lens, st.loop
 
@@ -117,9 +120,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    select_timing = []
+
     def step(timing):
         model.decoder.event_log = timing   # HIP events around every vocabulary-projection launch
-        tok, lens, loop = decode_batch(model, vocab, src, args.beam, args.alpha)
+        tok, lens, loop = decode_batch(model, vocab, src, args.beam, args.alpha, None if timing is None else select_timing)
         if world > 1:
             tok, lens = shard.gather_outputs(tok, lens, n_total, order, per_rank)
         tok_h, lens_h = tok.cpu(), lens.cpu()   # final device-to-host copy of the outputs
@@ -149,6 +154,12 @@ def main():
         gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in timing)
         gemm_flops = sum(f for _, _, f in timing)
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+        sel_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in select_timing)
+        sel_gbs = sum(b for _, _, b in select_timing) / (sel_ms * 1e-3) / 1e9 if sel_ms > 0 else 0.0
+        traffic = None   # HBM bytes per vocabulary-projection launch from the committed PMC passes of this command
+        if os.path.exists(TRAFFIC_FILE):
+            with open(TRAFFIC_FILE) as f:
+                traffic = json.load(f).get('hbm_bytes_per_launch')
         result = {
             'metric': 'decoded tokens/sec (beam=%d, 32k BPE)' % args.beam,
             'value': emitted / dt, 'unit': 'tokens/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -162,10 +173,15 @@ def main():
                        'decode_steps_per_batch': n_steps_loop / args.steps, 'row_steps_per_batch': rows_stepped / args.steps,
                        'parallelism': 'dp%d (sentence shards, all-gather of outputs)' % world},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                         'frac': achieved / FP32_MATRIX_PEAK_TFLOPS, 'traffic': None,
+                         'frac': achieved / FP32_MATRIX_PEAK_TFLOPS, 'traffic': traffic,
                          'kernel': 'gemm_f32_kernel (vocabulary projection [rows,256]x[256,32000], fp32 MFMA)',
                          'launches': len(timing), 'avg_launch_ms': gemm_ms / max(1, len(timing)),
                          'share_of_step_time': gemm_ms * 1e-3 / dt},
+            # second kernel by time, the HBM-bound pass over the [rows, V] logits (algorithmic bytes: every logit once)
+            'roofline_select': {'bound': 'hbm', 'achieved': sel_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                                'frac': sel_gbs / HBM_PEAK_GBS, 'kernel': 'logsoftmax_topk_kernel (log-sum-exp + top-%d over V=%d)'
+                                % (args.beam, VOCAB), 'launches': len(select_timing),
+                                'avg_launch_ms': sel_ms / max(1, len(select_timing)), 'share_of_step_time': sel_ms * 1e-3 / dt},
         }
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.eos_bias, args.cpu_sample)

@@ -126,6 +126,7 @@ class InferenceState:
         with torch.cuda.device(device):
             loop = DecodeLoop(self._session(), self.batch_size, self.beam_size, self.max_len, self.bos_idx,
                               self.eos_idx, self.pad_idx, self.length_penalty, device, sample)
+            loop.select_log = getattr(self, 'select_log', None)
             loop.run(keep_logits)
         self.loop = loop
         self.num_steps_done = loop.steps_done

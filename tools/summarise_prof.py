@@ -26,7 +26,8 @@ def label(name, grid, wg):
     key = name.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:90]
     if 'gemm_' in key:
         n = grid // max(1, wg)
-        key += ' [vocabulary projection]' if n >= 250 and n % 250 == 0 else ' [layer GEMMs]'
+        cols = 125 if '<2, 4,' in key else 250          # column tiles of N = 32000: 256- or 128-wide tiles
+        key += ' [vocabulary projection]' if n >= cols and n % cols == 0 else ' [layer GEMMs]'
     return key
 
 
