@@ -111,3 +111,62 @@ def test_config2_batch_order_independence_full_size(T, mt):
     perm = np.random.RandomState(9).permutation(8192)
     tok2, lens2, score2 = gpu_decode(T, model, vocab, src[perm], 4)
     assert np.array_equal(lens2, lens[perm]) and np.array_equal(tok2, tok[perm]) and np.array_equal(score2, score[perm])
+
+
+def test_config3_gru_full_batch_sample_vs_oracle(T):
+    """BASELINE config 3: GRU decoder E = H = 1024 (cyclegan sizes), character vocabulary, EOS '|', 8192
+    sentences, greedy and beam 4: 32 sampled sentences equal the oracle (tokens, beam scores) bit for bit."""
+    from tst_amd import synthetic
+    Vc = 128
+    vocab = T.Vocab.synthetic(Vc, extra=('|',))
+    model = T.RNNDecoder(1024, 1024, vocab)
+    model.load_state_dict(synthetic.synthetic_state_dict(model, vocab.stoi['|'], 0.5, 2.0, seed=42))
+    tv = R.synthetic_vocab(Vc, extra=('|',))
+    tmodel = R.synthetic_init(R.RNNDecoder(1024, 1024, tv), tv.stoi['|'], 0.5, 2.0, seed=42)
+    z = torch.randn((8192, 1024), generator=torch.Generator().manual_seed(1237))
+    pick = np.sort(np.random.RandomState(10).choice(8192, size=32, replace=False))
+    eos = vocab.stoi['|']
+    for beam in (1, 4):
+        st = T.InferenceState({'model': model, 'inputs': z.cuda(), 'vocab': vocab, 'max_len': 40, 'eos_token': '|',
+                               'beam_size': beam})
+        tok, lens, score = (x.cpu().numpy() for x in st.decode_packed())
+        sess = C.CanonGRUDecoder(tmodel).session(z[pick].numpy(), beam)
+        if beam == 1:
+            want = C.greedy_decode(sess, 32, 40, 2, eos)[0]
+        else:
+            want, wscore, _, _ = C.beam_decode(sess, 32, beam, 40, 2, eos)
+            assert np.array_equal(score[pick], wscore)
+        assert rows_as_lists(tok, lens, pick) == want
+        assert len(set(lens.tolist())) > 5
+
+
+def test_config4_lm_sizes_fp32_sample_and_bf16_properties(T):
+    """BASELINE config 4 sizes (model_size 512, 6 layers, 8 heads, d_ff 2048, V = 32000, beam 8).  fp32: 6 sampled
+    sentences of a 512-sentence batch equal the oracle bit for bit.  bf16 (checked by tolerance at small sizes
+    elsewhere): at this size the batch-order independence and the output format must hold."""
+    from tst_amd import synthetic
+    hp = dict(model_size=512, n_layers=6, n_heads=8, d_ff=2048, pe_max_len=64)
+    vocab = T.Vocab.synthetic(V)
+    tv = R.synthetic_vocab(V)
+    tmodel = R.synthetic_init(R.TransformerLM(R.HP(hp), tv), 3, 5.0, 2.0, seed=42)
+    z = 0.3 * torch.randn((512, 512), generator=torch.Generator().manual_seed(1238))
+    T_ = 12
+
+    def run(dtype, zz):
+        lm = T.TransformerLM(T.HP(hp), vocab, dtype=dtype)
+        lm.load_state_dict(tmodel.state_dict())
+        st = T.InferenceState({'model': lm, 'inputs': zz.cuda(), 'vocab': vocab, 'max_len': T_, 'beam_size': 8})
+        return tuple(x.cpu().numpy() for x in st.decode_packed())
+
+    tok, lens, score = run('fp32', z)
+    pick = np.sort(np.random.RandomState(11).choice(512, size=6, replace=False))
+    want, wscore, _, _ = C.beam_decode(C.CanonTransformerLM(tmodel).session(z[pick].numpy(), 8, T_), 6, 8, T_, 2, 3)
+    assert rows_as_lists(tok, lens, pick) == want
+    assert np.array_equal(score[pick], wscore)
+    tok16, lens16, score16 = run('bf16', z)
+    perm = np.random.RandomState(12).permutation(512)
+    tok16p, lens16p, score16p = run('bf16', z[perm])
+    assert np.array_equal(tok16p, tok16[perm]) and np.array_equal(lens16p, lens16[perm]) and np.array_equal(score16p, score16[perm])
+    assert (tok16[:, 0] == 2).all() and lens16.max() <= T_ + 1
+    agree = float(np.mean([a == b for a, b in zip(rows_as_lists(tok16, lens16, range(512)), rows_as_lists(tok, lens, range(512)))]))
+    print('\n[config 4] bf16 vs fp32 GPU path: %.0f %% of 512 beam-8 outputs identical' % (100 * agree))

@@ -1,0 +1,121 @@
+"""GPU: edge cases of the decode path — smallest and degenerate batches, immediate and never-occurring EOS,
+missing masks, odd vocabulary sizes, a foreign model under beam search — each against the canonical oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import canon as C
+from oracle import torch_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def T():
+    import tst_amd
+    assert torch.cuda.is_available()
+    return tst_amd
+
+
+def mt_case(T, V, B, S, eos_bias, seed, lens=None):
+    hp = R.mt_hp()
+    tv = R.synthetic_vocab(V)
+    tmodel = R.synthetic_init(R.Transformer(R.HP(hp), tv, tv), 3, eos_bias, 2.0, seed=seed)
+    vocab = T.Vocab.synthetic(V)
+    model = T.Transformer(T.HP(hp), vocab, vocab)
+    model.load_state_dict(tmodel.state_dict())
+    r = np.random.RandomState(seed)
+    lens = r.randint(1, S + 1, size=B) if lens is None else np.asarray(lens)
+    encs = r.standard_normal((B, S, hp['d_model'])).astype(np.float32)
+    mask = (np.arange(S)[None] < lens[:, None])[:, None, :]
+    return tmodel, model, vocab, encs, mask
+
+
+def decode(T, model, vocab, encs, mask, max_len, beam, **kw):
+    d = {'model': model.decoder, 'inputs': torch.from_numpy(encs).cuda(), 'vocab': vocab, 'max_len': max_len, 'beam_size': beam}
+    if mask is not None:
+        d['enc_mask'] = torch.from_numpy(mask).cuda()
+    d.update(kw)
+    st = T.InferenceState(d)
+    return [s.cpu().tolist() for s in st.inference()], st
+
+
+def oracle(tmodel, encs, mask, max_len, beam, alpha=0.0):
+    sess = C.CanonTransformerDecoder(tmodel.decoder, 2).session(encs, mask, beam, max_len)
+    if beam == 1:
+        return C.greedy_decode(sess, encs.shape[0], max_len, 2, 3)[0], None
+    seqs, scores, _, _ = C.beam_decode(sess, encs.shape[0], beam, max_len, 2, 3, alpha)
+    return seqs, scores
+
+
+@pytest.mark.parametrize('B,beam,max_len', [(1, 1, 1), (1, 8, 1), (1, 8, 9), (3, 4, 1), (2, 2, 30), (257, 3, 5)])
+def test_smallest_batches_and_single_steps(T, B, beam, max_len):
+    tmodel, model, vocab, encs, mask = mt_case(T, 300, B, 7, 2.0, 21)
+    got, st = decode(T, model, vocab, encs, mask, max_len, beam)
+    want, scores = oracle(tmodel, encs, mask, max_len, beam)
+    assert got == want
+    if scores is not None:
+        assert np.array_equal(st.scores.cpu().numpy(), scores)
+    assert all(s[0] == 2 and len(s) <= 1 + max_len for s in got)
+
+
+@pytest.mark.parametrize('beam', [1, 4])
+def test_every_sentence_ends_at_once_and_none_ever_ends(T, beam):
+    tmodel, model, vocab, encs, mask = mt_case(T, 200, 9, 6, 40.0, 22)          # EOS wins every arg-max
+    got, st = decode(T, model, vocab, encs, mask, 12, beam)
+    assert got == [[2]] * 9 and st.num_steps_done == 1
+    assert got == oracle(tmodel, encs, mask, 12, beam)[0]
+    tmodel, model, vocab, encs, mask = mt_case(T, 200, 9, 6, -40.0, 23)         # EOS never wins
+    got, st = decode(T, model, vocab, encs, mask, 12, beam)
+    assert all(len(s) == 13 and 3 not in s for s in got) and st.num_steps_done == 12
+    assert got == oracle(tmodel, encs, mask, 12, beam)[0]
+
+
+def test_no_mask_one_position_sources_and_max_positions(T):
+    tmodel, model, vocab, encs, mask = mt_case(T, 150, 5, 4, 1.5, 24)
+    got, _ = decode(T, model, vocab, encs, None, 10, 4)                          # enc_mask omitted: attend to everything
+    assert got == oracle(tmodel, encs, None, 10, 4)[0]
+    tmodel, model, vocab, encs, mask = mt_case(T, 150, 5, 4, 1.5, 25, lens=[1, 1, 4, 1, 2])
+    got, _ = decode(T, model, vocab, encs, mask, 10, 4)                          # a single unmasked source position
+    assert got == oracle(tmodel, encs, mask, 10, 4)[0]
+    tmodel, model, vocab, encs, mask = mt_case(T, 150, 3, 60, -30.0, 26)         # pe_max_len = 60: longest source, longest decode
+    got, _ = decode(T, model, vocab, encs, mask, 60, 2)
+    assert got == oracle(tmodel, encs, mask, 60, 2)[0] and all(len(s) == 61 for s in got)
+    with pytest.raises(ValueError, match='pe_max_len'):
+        decode(T, model, vocab, encs, mask, 61, 2)
+
+
+@pytest.mark.parametrize('V', [5, 37, 130, 1001])
+def test_odd_vocabulary_sizes_gru_greedy_beam_and_sampling(T, V):
+    """Vocabulary sizes that are not multiples of 4 / 16 (ragged last chunk of every kernel over V); beam up to V."""
+    tv = R.synthetic_vocab(V)
+    tmodel = R.synthetic_init(R.RNNDecoder(32, 64, tv), 3, 1.0, 2.0, seed=V)
+    vocab = T.Vocab.synthetic(V)
+    model = T.RNNDecoder(32, 64, vocab)
+    model.load_state_dict(tmodel.state_dict())
+    z = np.random.RandomState(V).standard_normal((11, 64)).astype(np.float32)
+    for beam in (1, min(5, V)):
+        st = T.InferenceState({'model': model, 'inputs': torch.from_numpy(z).cuda(), 'vocab': vocab, 'max_len': 9, 'beam_size': beam})
+        got = [s.cpu().tolist() for s in st.inference()]
+        sess = C.CanonGRUDecoder(tmodel).session(z, beam)
+        want = C.greedy_decode(sess, 11, 9, 2, 3)[0] if beam == 1 else C.beam_decode(sess, 11, beam, 9, 2, 3)[0]
+        assert got == want
+    st = T.InferenceState({'model': model, 'inputs': torch.from_numpy(z).cuda(), 'vocab': vocab, 'max_len': 9,
+                           'sample_type': 'sample', 'temperature': 1.7, 'seed': 4})
+    got = [s.cpu().tolist() for s in st.inference()]
+    assert got == C.greedy_decode(C.CanonGRUDecoder(tmodel).session(z), 11, 9, 2, 3, sample=(1.7, 4))[0]
+    with pytest.raises(ValueError):
+        T.InferenceState({'model': model, 'inputs': torch.from_numpy(z).cuda(), 'vocab': vocab, 'beam_size': 8 if V < 8 else 9}).inference()
+
+
+def test_foreign_model_under_beam_search(T):
+    """A model that is not from this package (the torch specification on the GPU, whole-prefix calls): beam search
+    reorders its inputs and mask through index_select; same sequences as the native model."""
+    tmodel, model, vocab, encs, mask = mt_case(T, 120, 6, 8, 1.0, 27)
+    import types
+    dec = tmodel.decoder.cuda()
+    st = T.InferenceState({'model': dec, 'inputs': torch.from_numpy(encs).cuda(), 'enc_mask': torch.from_numpy(mask).cuda(),
+                           'vocab': vocab, 'max_len': 10, 'beam_size': 3})
+    got = [s.cpu().tolist() for s in st.inference()]
+    native, _ = decode(T, model, vocab, encs, mask, 10, 3)
+    assert got == native
