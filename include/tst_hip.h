@@ -39,6 +39,12 @@ const char* tst_last_error(void);
 int tst_embed_posadd_f32(const int32_t* tok, const float* emb, const float* pe, const int32_t* pos, float scale, float* x,
                          int64_t R, int64_t d, int64_t V, void* stream);
 
+/* x[r][:] = x[r][:] * scale + pe[:]   (pe NULL: no add), in place.  The tail of an embedding that was computed
+ * as a product, token distributions [R][V] times the embedding matrix [V][d] (tst_gemm_mfma_f32), which is
+ * what a model does with the distributions that /root/reference/src/inference.py:104-105 feeds back under
+ * gumbel=True.  d % 4 == 0. */
+int tst_scale_posadd_f32(float* x, float scale, const float* pe, int64_t R, int64_t d, void* stream);
+
 /* y = LayerNorm(x) over the last dimension (biased variance), rows of d floats, d % 4 == 0. */
 int tst_layernorm_f32(const float* x, const float* gamma, const float* beta, float eps, float* y, int64_t R, int64_t d,
                       void* stream);
@@ -102,6 +108,14 @@ int tst_gather_rows_f32(const float* src, const int32_t* idx, float* dst, int64_
 /* tok[r] = index of the first maximal element of logits[r][0..V): torch.max(dim=-1)[1] at
  * /root/reference/src/inference.py:145. */
 int tst_argmax_rows_f32(const float* logits, int64_t ld, int64_t R, int64_t V, int32_t* tok, void* stream);
+
+/* out[r][:] = softmax((softmax(logits[r][:]) + G) / temperature), G = -log(-log(u[r][:] + 1e-20) + 1e-20):
+ * F.softmax(next_tokens_dists, dim=1) followed by gumbel_softmax_sample(.., temperature) at
+ * /root/reference/src/inference.py:137-138 (/root/reference/src/utils/gumbel.py:11-21).  u holds the uniform
+ * draws in [0, 1) that the reference takes from torch.rand; they are an input so that a caller reproduces the
+ * reference's noise stream.  out must not alias logits or u.  temperature > 0. */
+int tst_gumbel_softmax_f32(const float* logits, int64_t ld, int64_t R, int64_t V, const float* u, int64_t ldu,
+                           float temperature, float* out, int64_t ldo, void* stream);
 
 /* tok[r] ~ Categorical(logits = logits[r] / temperature): Categorical(...).sample() at
  * /root/reference/src/inference.py:147, drawn by the Gumbel-max trick, argmax_v (x_v / temperature - log(-log u_v)),

@@ -64,6 +64,36 @@ def synthetic_vocab(size, extra=()):
     return v
 
 
+def embed_tokens(embedding, ys):
+    """Embedding of token ids ``[B, t]`` or, for the soft decoding mode, the expected embedding of token
+    distributions ``[B, t, V]`` (a floating tensor): ``dist @ weight``."""
+    if ys.is_floating_point():
+        return torch.matmul(ys, embedding.weight)
+    return embedding(ys)
+
+
+def ref_gumbel_softmax(dists, u, temperature=1):
+    """``gumbel_softmax_sample`` of ``/root/reference/src/utils/gumbel.py:11-21`` with the uniform draws ``u`` given
+    (the reference takes them from ``torch.rand``): softmax((dists + G) / temperature), G = -log(-log(u + eps) + eps)."""
+    noise = -torch.log(-torch.log(u + 1e-20) + 1e-20)
+    return F.softmax((dists + noise) / temperature, dim=-1)
+
+
+class SoftInput(nn.Module):
+    """Adapter under which the gumbel branch of the reference loop runs
+    (``/root/reference/src/inference.py:104-105,136-138``): with ``gumbel=True`` the loop concatenates the
+    ``[B, 1, V]`` distributions along the LAST axis, so after t steps ``active_seqs`` is ``[B, 1, t * V]``; this
+    adapter views it as t distributions over V tokens and calls the wrapped model, whose embedding accepts
+    distributions (``embed_tokens``)."""
+
+    def __init__(self, model, vocab_size):
+        super().__init__()
+        self.model, self.V = model, vocab_size
+
+    def forward(self, inputs, active, *args, **kwargs):
+        return self.model(inputs, active.reshape(active.shape[0], -1, self.V), *args, **kwargs)
+
+
 # --------------------------------------------------------------------------------------------
 # Transformer (pre-norm encoder-decoder, sinusoidal positions, raw-logit output)
 # --------------------------------------------------------------------------------------------
@@ -195,7 +225,7 @@ class TransformerDecoder(nn.Module):
             mem_mask = torch.stack(list(enc_mask)).unsqueeze(1)
         t = ys.shape[1]
         causal = torch.ones(t, t, dtype=torch.bool, device=ys.device).tril().view(1, 1, t, t)
-        x = self.embed(ys) * math.sqrt(self.d_model) + self.pe[:t]
+        x = embed_tokens(self.embed, ys) * math.sqrt(self.d_model) + self.pe[:t]
         for layer in self.layers:
             x = layer(x, encs, causal, mem_mask)
         return self.out(self.ln(x))
@@ -278,7 +308,7 @@ class RNNDecoder(nn.Module):
         self.out = nn.Linear(hid_size, len(vocab))
 
     def forward(self, z, x):
-        hid, _ = self.gru(self.embed(x), z.unsqueeze(0))
+        hid, _ = self.gru(embed_tokens(self.embed, x), z.unsqueeze(0))
         return self.out(hid)
 
 
@@ -344,8 +374,10 @@ def synthetic_init(module, eos_idx=None, eos_bias=0.0, out_scale=1.0, seed=42):
 # --------------------------------------------------------------------------------------------
 class RefInferenceState:
     """Restatement of ``InferenceState`` (``/root/reference/src/inference.py:11-167``), greedy and
-    sampling selection, stateful (``substitute_inputs``) and full-prefix modes, without the gumbel
-    branch.  Keeps the reference's data flow: the whole prefix is fed to the model at every step
+    sampling selection, stateful (``substitute_inputs``) and full-prefix modes, and the gumbel branch
+    (``:104-105,136-138`` with ``/root/reference/src/utils/gumbel.py:11-21``; it needs a caller-provided
+    ``active_seqs`` of distributions ``[B, 1, V]`` and a model that takes them, see ``SoftInput``).  Keeps the
+    reference's data flow: the whole prefix is fed to the model at every step
     (``:132``), finished rows leave the batch (``:102-120``), a finished sequence is stored as it
     was *before* its EOS was appended (``:94-100``), unfinished rows are stored after ``max_len``
     steps (``:65-69``)."""
@@ -364,7 +396,8 @@ class RefInferenceState:
         self.inputs_batch_dim = state.get('inputs_batch_dim', 0)
         self.substitute_inputs = state.get('substitute_inputs', False)
         self.batch_size = self.inputs.size(self.inputs_batch_dim)
-        self.active = torch.full((self.batch_size, 1), self.bos_idx, dtype=torch.long)
+        self.gumbel = state.get('gumbel', False)
+        self.active = state.get('active_seqs', torch.full((self.batch_size, 1), self.bos_idx, dtype=torch.long))
         self.finished = [None] * self.batch_size
         self.active_idx = torch.arange(self.batch_size)
         self.step_logits = []  # last-position logits per step (rows = active rows of that step)
@@ -393,10 +426,15 @@ class RefInferenceState:
                     self.step_logits.append(logits.clone())
                     self.step_rows.append(self.active_idx.clone())
                 nxt = self._select(logits)
+                nxt_x = nxt
+                if self.gumbel:
+                    # softmax of the logits, Gumbel noise from torch's global generator, softmax again
+                    dists = F.softmax(logits, dim=1)
+                    nxt_x = ref_gumbel_softmax(dists, torch.rand(dists.size()), self.temperature)
                 done = nxt == self.eos_idx
                 for i, seq in zip(self.active_idx[done].tolist(), self.active[done]):
                     self.finished[i] = seq
-                self.active = torch.cat([self.active, nxt.unsqueeze(1)], dim=-1)[~done]
+                self.active = torch.cat([self.active, nxt_x.unsqueeze(1)], dim=-1)[~done]
                 self.active_idx = self.active_idx[~done]
                 self.inputs = self.inputs.index_select(self.inputs_batch_dim, (~done).nonzero().squeeze(1))
                 if self.enc_mask is not None:

@@ -198,6 +198,102 @@ def tlm_case(InferenceState, name, hp, V, B, max_len, eos_bias, out_scale, seed,
     save(name, config, {'z': z.numpy()}, seqs, rec, finished_lens_of(seqs, max_len))
 
 
+def gumbel_case(InferenceState, name, kind, V, B, max_len, temperature, eos_bias, out_scale, seed, noise_seed, keep=4):
+    """The gumbel branch of the reference loop (``/root/reference/src/inference.py:83-88,104-105,136-138``,
+    ``/root/reference/src/utils/gumbel.py:11-21``): it runs when the caller provides ``active_seqs`` as
+    distributions ``[B, 1, V]`` (one-hot BOS here) and a model that takes distributions
+    (``oracle.torch_ref.SoftInput``).  The uniform draws of ``torch.rand`` are recorded per step so that the
+    noise does not depend on a torch version; outputs are the ``[1, t * V]`` tensors the loop returns."""
+    import src.utils.gumbel as G
+    rs = np.random.RandomState(seed)
+    arrays = {}
+    if kind == 'gru':
+        vocab = R.synthetic_vocab(V, extra=('|',))
+        model = R.synthetic_init(R.RNNDecoder(32, 32, vocab), vocab.stoi['<eos>'], eos_bias, out_scale, seed=42)
+        inputs = torch.from_numpy(rs.standard_normal((B, 32)).astype(np.float32))
+        arrays['z'] = inputs.numpy()
+        enc_mask = None
+        core = model
+        extra = dict(E=32, H=32)
+    else:
+        vocab = R.synthetic_vocab(V)
+        hp = R.mt_hp()
+        model = R.synthetic_init(R.Transformer(hp, vocab, vocab), vocab.stoi['<eos>'], eos_bias, out_scale, seed=42)
+        S = 10
+        lens = rs.randint(3, S + 1, size=B)
+        inputs = torch.from_numpy(rs.standard_normal((B, S, hp.d_model)).astype(np.float32))
+        enc_mask = torch.from_numpy(np.arange(S)[None, :] < lens[:, None]).unsqueeze(1)
+        arrays['encs'], arrays['enc_mask'] = inputs.numpy(), enc_mask.numpy()
+        core = model.decoder
+        extra = dict(hp=dict(hp))
+    rec = Recorder(R.SoftInput(core, V), keep)
+    prefix = torch.zeros(B, 1, V)
+    prefix[:, 0, vocab.stoi['<bos>']] = 1.0
+    draws = []
+    real_rand = torch.rand
+
+    def recording_rand(*a, **kw):
+        u = real_rand(*a, **kw)
+        draws.append(u.clone().numpy())
+        return u
+
+    state = {'model': rec, 'inputs': inputs, 'vocab': vocab, 'max_len': max_len, 'gumbel': True,
+             'temperature': temperature, 'active_seqs': prefix}
+    if enc_mask is not None:
+        state['enc_mask'] = enc_mask
+    torch.manual_seed(noise_seed)
+    torch.rand = recording_rand
+    try:
+        with torch.no_grad():
+            seqs = InferenceState(state).inference()
+    finally:
+        torch.rand = real_rand
+    lens_out = np.array([s.shape[1] // V for s in seqs], dtype=np.int32)
+    dists = np.zeros((B, int(lens_out.max()), V), dtype=np.float32)
+    for i, sq in enumerate(seqs):
+        assert tuple(sq.shape) == (1, lens_out[i] * V)
+        dists[i, :lens_out[i]] = sq.reshape(-1, V).numpy()
+    out = dict(arrays, dists=dists, lens=lens_out)
+    for i, u in enumerate(draws):
+        out['u_s%d' % i] = u.astype(np.float32)
+    for i, lg in enumerate(rec.logits):
+        out['logits_s%d' % i] = lg.astype(np.float32)
+    config = dict(kind='gumbel_' + kind, V=V, weight_seed=42, eos_bias=eos_bias, out_scale=out_scale, max_len=max_len,
+                  temperature=temperature, data_seed=seed, noise_seed=noise_seed, n_steps=len(draws),
+                  source='reference src/inference.py (gumbel=True) + src/utils/gumbel.py', **extra)
+    out['config'] = np.frombuffer(json.dumps(config).encode(), dtype=np.uint8)
+    np.savez_compressed(os.path.join(HERE, name + '.npz'), **out)
+    print('%-16s B=%d lens=%s steps=%d' % (name, B, lens_out.tolist(), len(draws)))
+
+
+def gumbel_op_case():
+    """Outputs of the reference's own ``gumbel_softmax_sample`` (``/root/reference/src/utils/gumbel.py:18-21``) on
+    fixed inputs, with the uniform draws recorded."""
+    import src.utils.gumbel as G
+    rs = np.random.RandomState(11)
+    out = {}
+    real_rand = torch.rand
+    for i, (rows, V, temp, scale) in enumerate(((5, 37, 1.0, 1.0), (3, 1000, 0.5, 3.0), (2, 4099, 2.0, 1.0))):
+        logits = torch.from_numpy((scale * rs.standard_normal((rows, V))).astype(np.float32))
+        draws = []
+
+        def recording_rand(*a, **kw):
+            u = real_rand(*a, **kw)
+            draws.append(u.clone().numpy())
+            return u
+
+        torch.manual_seed(100 + i)
+        torch.rand = recording_rand
+        try:
+            y = G.gumbel_softmax_sample(torch.softmax(logits, dim=1), temp)   # as src/inference.py:137-138 calls it
+        finally:
+            torch.rand = real_rand
+        out['logits_%d' % i], out['u_%d' % i], out['y_%d' % i] = logits.numpy(), draws[0], y.numpy()
+        out['temp_%d' % i] = np.float32(temp)
+    np.savez_compressed(os.path.join(HERE, 'gumbel_op.npz'), **out)
+    print('gumbel_op        3 cases')
+
+
 def postprocess_case():
     """Outputs of the reference's own ``itos_many`` and ``compute_bleu_for_sents`` on synthetic sentences."""
     from src.utils.data_utils import itos_many
@@ -251,6 +347,11 @@ def main():
              max_len=14, eos_bias=4.0, out_scale=2.0, seed=106)
     stateful_case(InferenceState, 'rnnlm_stateful', H=64, V=50, n_layers=2, B=4, max_len=14, eos_bias=1.0,
                   out_scale=2.0, seed=105)
+    gumbel_op_case()
+    gumbel_case(InferenceState, 'gumbel_gru', 'gru', V=40, B=5, max_len=10, temperature=0.7, eos_bias=1.0, out_scale=2.0,
+                seed=107, noise_seed=7)
+    gumbel_case(InferenceState, 'gumbel_tfm', 'tfm', V=64, B=4, max_len=9, temperature=1.0, eos_bias=1.5, out_scale=2.0,
+                seed=108, noise_seed=8)
 
 
 if __name__ == '__main__':

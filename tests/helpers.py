@@ -14,9 +14,36 @@ GOLDEN = os.path.join(ROOT, 'tests', 'golden')
 def load_fixture(name):
     z = np.load(os.path.join(GOLDEN, name + '.npz'))
     fx = {k: z[k] for k in z.files}
-    fx['config'] = json.loads(bytes(fx['config']).decode())
-    fx['seqs'] = [fx['tokens'][i, :n].tolist() for i, n in enumerate(fx['lens'])]
+    if 'config' in fx:
+        fx['config'] = json.loads(bytes(fx['config']).decode())
+    if 'tokens' in fx:
+        fx['seqs'] = [fx['tokens'][i, :n].tolist() for i, n in enumerate(fx['lens'])]
     return fx
+
+
+class replay_rand:
+    """Context manager: ``torch.rand`` returns the recorded uniform draws of a fixture, one array per call (the
+    reference draws its Gumbel noise with ``torch.rand``: /root/reference/src/utils/gumbel.py:12)."""
+
+    def __init__(self, draws):
+        self.draws, self.i = list(draws), 0
+
+    def __enter__(self):
+        import torch
+        self.real = torch.rand
+
+        def fake(*size, **kw):
+            shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+            u = torch.from_numpy(np.array(self.draws[self.i]))
+            assert tuple(u.shape) == shape, (self.i, tuple(u.shape), shape)
+            self.i += 1
+            return u.to(kw['device']) if 'device' in kw else u
+        torch.rand = fake
+        return self
+
+    def __exit__(self, *exc):
+        import torch
+        torch.rand = self.real
 
 
 def torch_model_for(cfg):
@@ -24,7 +51,7 @@ def torch_model_for(cfg):
     the config: ``oracle.torch_ref.synthetic_init``)."""
     from oracle import torch_ref as R
     kind = cfg['kind']
-    if kind == 'transformer':
+    if kind in ('transformer', 'gumbel_tfm'):
         vocab = R.synthetic_vocab(cfg['V'])
         model = R.synthetic_init(R.Transformer(R.HP(cfg['hp']), vocab, vocab), vocab.stoi['<eos>'], cfg['eos_bias'],
                                  cfg['out_scale'], seed=cfg['weight_seed'])
@@ -35,9 +62,9 @@ def torch_model_for(cfg):
                                  cfg['out_scale'], seed=cfg['weight_seed'])
         return model, vocab
     vocab = R.synthetic_vocab(cfg['V'], extra=('|',))
-    if kind == 'gru':
+    if kind in ('gru', 'gumbel_gru'):
         model = R.RNNDecoder(cfg['E'], cfg['H'], vocab)
-        eos = vocab.stoi[cfg['eos_token']]
+        eos = vocab.stoi[cfg.get('eos_token', '<eos>')]
     elif kind == 'rnnlm_stateful':
         model = R.RNNLM(cfg['H'], vocab, cfg['n_layers'])
         eos = vocab.stoi['|']

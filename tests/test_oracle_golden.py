@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import load_fixture, logits_close, torch_model_for
+from helpers import load_fixture, logits_close, replay_rand, torch_model_for
 from oracle import canon as C
 from oracle import torch_ref as R
 
@@ -123,3 +123,35 @@ def test_sampler_follows_the_categorical_distribution():
     b = C.sample_rows(np.tile(x, (50, 1))[::-1].copy(), 1.0, seed=1, step=0, sent=np.arange(50)[::-1].copy())
     assert np.array_equal(a, b[::-1])         # a sentence's draw does not depend on its row in the batch
     assert not np.array_equal(a, C.sample_rows(np.tile(x, (50, 1)), 1.0, seed=2, step=0, sent=np.arange(50)))
+
+
+def test_gumbel_op_restatement_matches_reference_function():
+    """``oracle.torch_ref.ref_gumbel_softmax`` against outputs of the reference's own ``gumbel_softmax_sample``."""
+    fx = load_fixture('gumbel_op')
+    for i in range(3):
+        y = R.ref_gumbel_softmax(torch.softmax(torch.from_numpy(fx['logits_%d' % i]), dim=1), torch.from_numpy(fx['u_%d' % i]),
+                                 float(fx['temp_%d' % i]))
+        assert np.array_equal(y.numpy(), fx['y_%d' % i])
+
+
+@pytest.mark.parametrize('name', ['gumbel_gru', 'gumbel_tfm'])
+def test_gumbel_restatement_matches_reference_fixture(name):
+    """The gumbel branch of the restated loop against the real loop's outputs (same uniform draws)."""
+    fx = load_fixture(name)
+    cfg = fx['config']
+    model, vocab = torch_model_for(cfg)
+    V = cfg['V']
+    prefix = torch.zeros(fx['dists'].shape[0], 1, V)
+    prefix[:, 0, vocab.stoi['<bos>']] = 1.0
+    state = {'vocab': vocab, 'max_len': cfg['max_len'], 'gumbel': True, 'temperature': cfg['temperature'], 'active_seqs': prefix}
+    if cfg['kind'] == 'gumbel_gru':
+        state.update(model=R.SoftInput(model, V), inputs=torch.from_numpy(fx['z']))
+    else:
+        state.update(model=R.SoftInput(model.decoder, V), inputs=torch.from_numpy(fx['encs']),
+                     enc_mask=torch.from_numpy(fx['enc_mask']))
+    with replay_rand([fx['u_s%d' % i] for i in range(cfg['n_steps'])]):
+        out = R.RefInferenceState(state).inference()
+    assert [o.shape[1] // V for o in out] == fx['lens'].tolist()
+    for i, o in enumerate(out):
+        assert tuple(o.shape) == (1, fx['lens'][i] * V)
+        assert np.array_equal(o.reshape(-1, V).numpy(), fx['dists'][i, :fx['lens'][i]])

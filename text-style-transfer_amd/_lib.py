@@ -26,6 +26,7 @@ _PROTOS = {
     'tst_version': ([], c_int),
     'tst_last_error': ([], ctypes.c_char_p),
     'tst_embed_posadd_f32': ([c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
+    'tst_scale_posadd_f32': ([c_vp, c_f32, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_layernorm_f32': ([c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_gemm_mfma_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp], c_int),
     'tst_attn_self_step_f32': ([c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
@@ -33,6 +34,7 @@ _PROTOS = {
     'tst_gru_cell_step_f32': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_gather_rows_f32': ([c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_argmax_rows_f32': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_vp], c_int),
+    'tst_gumbel_softmax_f32': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp, c_i64, c_vp], c_int),
     'tst_sample_rows_f32': ([c_vp, c_i64, c_i64, c_i64, c_f32, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp, c_vp], c_int),
     'tst_logsoftmax_topk_f32': ([c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp], c_int),
     'tst_layernorm_f32_bf16': ([c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_vp], c_int),

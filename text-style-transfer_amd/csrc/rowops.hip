@@ -24,6 +24,21 @@ __global__ __launch_bounds__(256) void embed_posadd_kernel(const int32_t* __rest
     reinterpret_cast<float4*>(x)[i] = o;
 }
 
+// x = x * scale + pe (one thread per float4): the tail of an embedding that was computed as a product
+// (token distributions times the embedding matrix) instead of a row lookup
+__global__ __launch_bounds__(256) void scale_posadd_kernel(float* __restrict__ x, float scale, const float* __restrict__ pe,
+                                                           int64_t R, int d4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * d4) return;
+    float4 o = reinterpret_cast<float4*>(x)[i];
+    o.x = o.x * scale; o.y = o.y * scale; o.z = o.z * scale; o.w = o.w * scale;
+    if (pe != nullptr) {
+        const float4 p = reinterpret_cast<const float4*>(pe)[i % d4];
+        o.x = o.x + p.x; o.y = o.y + p.y; o.z = o.z + p.z; o.w = o.w + p.w;
+    }
+    reinterpret_cast<float4*>(x)[i] = o;
+}
+
 __device__ __forceinline__ void store4(float* y, int64_t i4, const float4& o) { reinterpret_cast<float4*>(y)[i4] = o; }
 __device__ __forceinline__ void store4(__bf16* y, int64_t i4, const float4& o) {
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -136,6 +151,17 @@ extern "C" int tst_embed_posadd_f32(const int32_t* tok, const float* emb, const 
     hipLaunchKernelGGL(embed_posadd_kernel, dim3(blocks_for(R * (d / 4), 256)), dim3(256), 0, (hipStream_t)stream, tok, emb,
                        pe, pos, scale, x, R, (int)(d / 4), V);
     return tst_after_launch("tst_embed_posadd_f32");
+}
+
+extern "C" int tst_scale_posadd_f32(float* x, float scale, const float* pe, int64_t R, int64_t d, void* stream) {
+    TST_REQUIRE(x, TST_ERR_ARG, "tst_scale_posadd_f32: null pointer");
+    TST_REQUIRE(R >= 0 && d > 0 && d % 4 == 0, TST_ERR_ARG, "tst_scale_posadd_f32: need d %% 4 == 0");
+    TST_REQUIRE(tst_aligned16(x) && tst_aligned16(pe), TST_ERR_ARG, "tst_scale_posadd_f32: alignment");
+    TST_REQUIRE(R * (d / 4) < (1ll << 31) * 256, TST_ERR_UNSUPPORTED, "tst_scale_posadd_f32: too large");
+    if (R == 0) return TST_OK;
+    hipLaunchKernelGGL(scale_posadd_kernel, dim3(blocks_for(R * (d / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, scale, pe,
+                       R, (int)(d / 4));
+    return tst_after_launch("tst_scale_posadd_f32");
 }
 
 extern "C" int tst_layernorm_f32(const float* x, const float* gamma, const float* beta, float eps, float* y, int64_t R,

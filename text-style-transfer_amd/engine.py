@@ -11,6 +11,7 @@ A *session* provides:
   ``needs_anc``       whether it reads the ancestor table (incremental KV cache)
   ``step(rows, n_rows, t) -> logits``   fp32 GPU tensor [>= n_rows, >= V], unit inner stride
   ``reorder(row_parent, n_rows, identity)``  called after each step with the old row of every new row
+  ``takes_soft``      (optional) ``step`` accepts ``soft=`` token distributions [rows, Vp] in place of ``rows.tok``
 Rows: step 0 has one row per sentence (row a = sentence a, per-sentence state in rows 0..B-1 of buffers sized
 for B * beam rows); the first ``reorder`` fans every sentence out to ``beam`` consecutive rows.
 """
@@ -25,7 +26,7 @@ def length_penalty_table(max_len, alpha):
 
 
 class DecodeLoop:
-    def __init__(self, session, n_sent, beam, max_len, bos, eos, pad, alpha=0.0, device=None, sample=None):
+    def __init__(self, session, n_sent, beam, max_len, bos, eos, pad, alpha=0.0, device=None, sample=None, gumbel=None):
         if not (1 <= beam <= 8):
             raise ValueError('beam_size must be in 1..8')
         if beam > session.V:
@@ -61,6 +62,24 @@ class DecodeLoop:
             self.top_val = torch.zeros((R, beam), dtype=torch.float32, device=dev)
             self.top_idx = torch.zeros((R, beam), **i32)
             self.lse = torch.zeros(R, dtype=torch.float32, device=dev)
+        # Soft decoding (``gumbel=True`` of /root/reference/src/inference.py:104-105,136-138): the next input of a row
+        # is the distribution softmax((softmax(logits) + G) / temperature) instead of a token id; the token that
+        # decides about EOS is still the arg-max / sample of the raw logits.  gumbel = (temperature, prefix [B, V],
+        # draw(n_rows, V) -> uniform numbers on the device).  dist_seq keeps every sentence's distributions.
+        self.gumbel = gumbel
+        if gumbel is not None:
+            if beam != 1:
+                raise ValueError('gumbel decoding and beam search cannot be combined')
+            if not getattr(session, 'takes_soft', False):
+                raise NotImplementedError('this model cannot be stepped on token distributions')
+            V = session.V
+            self.Vp = (V + 3) // 4 * 4
+            f32 = dict(dtype=torch.float32, device=dev)
+            self.dist_seq = torch.zeros((n_sent, max_len + 1, V), **f32)
+            self.dist_in = torch.zeros((n_sent, self.Vp), **f32)     # input of the coming step, one row per live row
+            self.dist_out = torch.zeros((n_sent, self.Vp), **f32)    # output of the step, before compaction
+            self.dist_in[:, :V] = gumbel[1]
+            self.dist_seq[:, 0] = gumbel[1]
         self.steps_done = 0
         self.rows_stepped = 0
         self.select_log = None   # set to a list to collect (start, end, bytes) of every log-softmax/top-k launch
@@ -75,7 +94,10 @@ class DecodeLoop:
         for t in range(T):
             k_in = 1 if t == 0 else k      # rows per sentence going into this step
             R = n_sent * k_in
-            logits = s.step(self.cur, R, t)
+            if self.gumbel is None:
+                logits = s.step(self.cur, R, t)
+            else:
+                logits = s.step(self.cur, R, t, soft=self.dist_in)
             if t < keep_logits:
                 self.kept.append((logits[:R, :s.V].clone(), self.cur.sent[:R].clone(), self.cur.fin[:R].clone()))
             if k == 1:
@@ -84,6 +106,10 @@ class DecodeLoop:
                 else:
                     K.sample_rows(logits, R, s.V, self.sample[0], self.sample[1], t, self.cur.sent, self.am)
                 K.greedy_select(self.am, R, self.eos, self.sel, self.cur)
+                if self.gumbel is not None:
+                    u = self.gumbel[2](R, s.V)
+                    K.gumbel_softmax(logits, R, s.V, u, self.gumbel[0], self.dist_out)
+                    self.dist_seq[:, t + 1].index_copy_(0, self.cur.sent[:R].long(), self.dist_out[:R, :s.V])
             else:
                 if self.select_log is None:
                     K.logsoftmax_topk(logits, R, s.V, k, self.top_val, self.top_idx, self.lse)
@@ -103,5 +129,7 @@ class DecodeLoop:
             if alive == 0:
                 break
             s.reorder(self.row_parent, alive * k, identity=(k == 1 and alive == n_sent))
+            if self.gumbel is not None:
+                K.gather_rows(self.dist_out, self.row_parent, self.dist_in, alive)
             n_sent = alive
         return self.out_tok, self.out_len, self.out_score

@@ -10,7 +10,18 @@ incrementally (KV cache / carried GRU state) instead of being re-run on the whol
 Additive keys (not in the reference): ``beam_size`` (1 = the reference's greedy arg-max; the reference
 has no beam search), ``length_penalty`` (alpha of ((5 + n) / 6) ** alpha, used to rank finished beams),
 ``seed`` (makes ``sample_type='sample'`` reproducible; by default a seed is drawn from torch's generator,
-so ``torch.manual_seed`` governs it like it governs the reference's ``Categorical.sample``).
+so ``torch.manual_seed`` governs it like it governs the reference's ``Categorical.sample``),
+``noise`` (gumbel mode: ``'torch'``, the default, draws the uniform numbers with ``torch.rand`` from the global
+CPU generator exactly as ``/root/reference/src/utils/gumbel.py:12`` does and copies them to the GPU, so the same
+``torch.manual_seed`` gives the reference's noise; ``'device'`` draws them on the GPU).
+
+``gumbel=True`` (``:83-88,104-105,136-138``): every step appends the distribution
+softmax((softmax(logits) + G) / temperature) instead of a token id, and the model is fed distributions.  In the
+reference this only runs when the caller passes ``active_seqs`` as distributions ``[B, 1, V]`` (ids cannot be
+concatenated with them) and the concatenation is along the last axis, so a result is a ``[1, t * V]`` tensor: t
+distributions back to back, the prefix first, the distribution of the step that chose EOS left out.  The same
+here; without ``active_seqs`` a one-hot BOS prefix is used (the reference raises there).  Models of this
+package embed a distribution as ``dist @ embedding``; any other callable gets ``[B, 1, t * V]`` as in the reference.
 
 Any other callable works as ``model`` too (the reference's protocol ``model(inputs, active_seqs, *args,
 **kwargs) -> [B, t, V]`` or ``(logits, new_inputs)`` with ``substitute_inputs``); it is then called once
@@ -24,6 +35,7 @@ from .engine import DecodeLoop
 class ForeignSession:
     """Steps an arbitrary model callable with the reference's protocol (``/root/reference/src/inference.py:122-132``)."""
     needs_anc = False
+    takes_soft = True
 
     def __init__(self, model, inputs, enc_mask, kwargs, substitute_inputs, inputs_batch_dim, beam, vocab_size):
         if inputs_batch_dim not in (0, 1, 2):
@@ -31,9 +43,17 @@ class ForeignSession:
         self.model, self.kwargs, self.sub, self.dim = model, kwargs, substitute_inputs, inputs_batch_dim
         self.inputs, self.enc_mask = inputs, enc_mask   # one row per sentence until the first reorder fans out
         self.V = vocab_size
+        self.soft_hist = None   # gumbel mode: the distributions fed so far, [rows, t, V]
 
-    def step(self, rows, n, t):
-        active = rows.hist[:n, :t + 1].long()
+    def step(self, rows, n, t, soft=None):
+        if soft is None:
+            active = rows.hist[:n, :t + 1].long()
+        else:   # [n, 1, (t + 1) * V]: the distributions back to back, as /root/reference/src/inference.py:105 builds them
+            new = soft[:n, :self.V].unsqueeze(1)
+            self.soft_hist = new.clone() if self.soft_hist is None else torch.cat([self.soft_hist, new], dim=1)
+            active = self.soft_hist.reshape(n, 1, -1)
+            if self.sub:
+                raise NotImplementedError('gumbel decoding of a stateful model')
         args = [] if self.enc_mask is None else self.enc_mask
         with torch.no_grad():
             if self.sub:
@@ -52,6 +72,8 @@ class ForeignSession:
         self.inputs = self.inputs.index_select(self.dim, idx)
         if self.enc_mask is not None:
             self.enc_mask = self.enc_mask.index_select(0, idx)
+        if self.soft_hist is not None:
+            self.soft_hist = self.soft_hist.index_select(0, idx)
 
 
 class InferenceState:
@@ -86,6 +108,7 @@ class InferenceState:
         self.beam_size = state_dict.get('beam_size', 1)
         self.length_penalty = state_dict.get('length_penalty', 0.0)
         self.seed = state_dict.get('seed')  # sampling only; default: drawn from torch's global generator
+        self.noise = state_dict.get('noise', 'torch')  # gumbel only: where the uniform draws come from
 
         self.finished = [None for _ in range(self.batch_size)]
         self.num_steps_done = 0
@@ -116,16 +139,36 @@ class InferenceState:
                 raise ValueError("sample_type='sample' needs beam_size 1")
             seed = self.seed if self.seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
             sample = (float(self.temperature), seed)
-        if self.gumbel:
-            raise NotImplementedError('gumbel decoding is not available in this build yet')
-        if self.active_seqs is not None:
-            raise NotImplementedError('a caller-provided active_seqs prefix is not supported')
+        if self.active_seqs is not None and not self.gumbel:
+            raise NotImplementedError('a caller-provided active_seqs prefix is only supported with gumbel=True')
         if not torch.cuda.is_available():
             raise RuntimeError('InferenceState needs a GPU: the decode loop runs in HIP kernels and has no CPU path')
         device = self.inputs.device if self.inputs.is_cuda else torch.device('cuda', torch.cuda.current_device())
+        gumbel = None
+        if self.gumbel:
+            if self.beam_size != 1:
+                raise ValueError('gumbel=True needs beam_size 1')
+            if self.substitute_inputs:
+                # /root/reference/src/inference.py:128 slices [B, 1, t * V] along its middle axis: empty from step 1 on
+                raise NotImplementedError('gumbel decoding of a stateful model')
+            if self.noise not in ('torch', 'device'):
+                raise ValueError("noise must be 'torch' or 'device'")
+            V = len(self.vocab)
+            if self.active_seqs is None:
+                prefix = torch.zeros((self.batch_size, V), dtype=torch.float32, device=device)
+                prefix[:, self.bos_idx] = 1.0
+            else:
+                if tuple(self.active_seqs.shape) != (self.batch_size, 1, V) or not self.active_seqs.is_floating_point():
+                    raise NotImplementedError('gumbel=True takes active_seqs as one distribution per sentence: [B, 1, V] floats')
+                prefix = self.active_seqs[:, 0].to(device=device, dtype=torch.float32)
+            if self.noise == 'torch':
+                draw = lambda n, v: torch.rand((n, v)).to(device)            # noqa: E731
+            else:
+                draw = lambda n, v: torch.rand((n, v), device=device)        # noqa: E731
+            gumbel = (float(self.temperature), prefix, draw)
         with torch.cuda.device(device):
             loop = DecodeLoop(self._session(), self.batch_size, self.beam_size, self.max_len, self.bos_idx,
-                              self.eos_idx, self.pad_idx, self.length_penalty, device, sample)
+                              self.eos_idx, self.pad_idx, self.length_penalty, device, sample, gumbel)
             loop.select_log = getattr(self, 'select_log', None)
             loop.run(keep_logits)
         self.loop = loop
@@ -143,6 +186,14 @@ class InferenceState:
     def inference(self, keep_logits=0):
         loop = self._run(keep_logits)
         lens = loop.out_len.cpu().tolist()
+        if self.gumbel:
+            # [1, t * V] per sentence, as the reference's last-axis concatenation leaves them
+            self.finished = [loop.dist_seq[i, :n].reshape(1, -1) for i, n in enumerate(lens)]
+            if self.should_stack_finished:
+                # every sequence has length 1 along dim 0, so /root/reference/src/inference.py:71-78 pads nothing
+                # and stacks; torch.stack raises for sequences of different numbers of steps, as it does there
+                self.finished = torch.stack(self.finished)
+            return self.finished
         toks = loop.out_tok.long()
         self.finished = [toks[i, :n] for i, n in enumerate(lens)]
         if self.should_stack_finished:

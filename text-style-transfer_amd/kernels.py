@@ -35,6 +35,25 @@ def embed_posadd(tok, emb, pe, scale, out, n_rows, pos=None):
     call('tst_embed_posadd_f32', _p(tok), _p(emb), _p(pe), _p(pos), float(scale), _p(out), n_rows, d, V, _stream())
 
 
+def soft_embed(dist, emb_pad, scale, pe, out, n_rows):
+    """out[:n_rows] = (dist[:n_rows] @ emb_pad) * scale + pe: the embedding of token distributions.  ``dist`` is
+    [rows, Vp] with Vp = V rounded up to a multiple of 4 (zero columns beyond V), ``emb_pad`` [Vp, d] (zero rows beyond V)."""
+    gemm(dist, emb_pad, None, out, n_rows)
+    if scale != 1.0 or pe is not None:
+        _chk(pe, torch.float32, 'pe')
+        call('tst_scale_posadd_f32', _p(out), float(scale), _p(pe), n_rows, out.shape[1], _stream())
+
+
+def gumbel_softmax(logits, n_rows, n_cols, u, temperature, out):
+    """out[:n_rows, :n_cols] = softmax((softmax(logits) + gumbel(u)) / temperature); 2-D fp32 views, unit inner stride"""
+    for t, nm in ((logits, 'logits'), (u, 'u'), (out, 'out')):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1):
+            raise ValueError('%s must be an fp32 GPU tensor with unit inner stride' % nm)
+    assert min(logits.shape[0], u.shape[0], out.shape[0]) >= n_rows and min(logits.shape[1], u.shape[1], out.shape[1]) >= n_cols
+    call('tst_gumbel_softmax_f32', _p(logits), logits.stride(0), n_rows, n_cols, _p(u), u.stride(0), float(temperature),
+         _p(out), out.stride(0), _stream())
+
+
 def layernorm(x, gamma, beta, out, n_rows, eps=1e-5):
     """out = LayerNorm(x); ``out`` is fp32, or bf16 when it feeds a bf16 GEMM"""
     _chk(x, torch.float32, 'x'); _chk(gamma, torch.float32, 'gamma'); _chk(beta, torch.float32, 'beta')

@@ -14,7 +14,7 @@ from collections import OrderedDict
 import torch
 
 from . import kernels as K
-from .transformer import HipModule, _t
+from .transformer import HipModule, _pad_rows4, _t
 
 
 class _GRUModel(HipModule):
@@ -45,6 +45,12 @@ class _GRUModel(HipModule):
             W['wout'], W['bout'] = _t(P['out.weight']), P['out.bias']
             self._prepared = W
         return self._prepared
+
+    def soft_embedding_matrix(self):
+        W = self.prepared()
+        if 'emb_pad' not in W:
+            W['emb_pad'] = _pad_rows4(W['emb'])
+        return W['emb_pad']
 
     def session(self, z, enc_mask=None, rows_per_sentence=1, max_len=None):
         return GRUSession(self, z, rows_per_sentence)
@@ -83,6 +89,7 @@ class GRUSession:
     """Carried hidden state [layer][row][H] (two buffers per layer: rows are re-gathered when the batch
     is compacted or beams are reordered) and work buffers."""
     needs_anc = False
+    takes_soft = True
 
     def __init__(self, model, z, k):
         self.m, self.V = model, model.V
@@ -112,9 +119,12 @@ class GRUSession:
             K.gather_rows(self.h[l], row_parent, self.h_alt[l], n_rows)
             self.h[l], self.h_alt[l] = self.h_alt[l], self.h[l]
 
-    def step(self, rows, n, t):
+    def step(self, rows, n, t, soft=None):
         m, W = self.m, self.m.prepared()
-        K.embed_posadd(rows.tok, W['emb'], None, 1.0, self.x, n)
+        if soft is None:
+            K.embed_posadd(rows.tok, W['emb'], None, 1.0, self.x, n)
+        else:   # token distributions instead of ids: expected embedding
+            K.soft_embed(soft, m.soft_embedding_matrix(), 1.0, None, self.x, n)
         x = self.x
         for l, c in enumerate(W['cells']):
             K.gemm(x, c['wih'], c['bih'], self.gi, n)

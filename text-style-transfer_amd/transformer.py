@@ -93,6 +93,15 @@ def _t(w):
     return wt[:, :out_f]
 
 
+def _pad_rows4(m):
+    rows = (m.shape[0] + 3) // 4 * 4
+    if rows == m.shape[0]:
+        return m
+    out = torch.zeros((rows, m.shape[1]), dtype=m.dtype, device=m.device)
+    out[:m.shape[0]] = m
+    return out
+
+
 def _normalise_mask(enc_mask, B, S, device):
     """Accepts [B,1,S] / [B,S] bool or byte masks, or the B rows [1,S] that
     ``/root/reference/src/inference.py:124,132`` produces by star-unpacking; returns uint8 [B,S] or None."""
@@ -176,6 +185,14 @@ class TransformerDecoder(HipModule):
             self._prepared = W
         return self._prepared
 
+    def soft_embedding_matrix(self):
+        """Embedding matrix with the vocabulary padded to a multiple of 4 rows (zeros): the right-hand side of the
+        product that embeds token distributions."""
+        W = self.prepared()
+        if 'emb_pad' not in W:
+            W['emb_pad'] = _pad_rows4(W['emb'])
+        return W['emb_pad']
+
     # ---- step-wise protocol used by the decode loop -------------------------------------------------
     def session(self, encs, enc_mask, rows_per_sentence, max_len):
         return TransformerSession(self, encs, enc_mask, rows_per_sentence, max_len)
@@ -201,6 +218,7 @@ class TransformerSession:
     """Per-batch decode state of a ``TransformerDecoder``: cross-attention k|v of the encoder outputs
     (computed once), the self-attention q|k|v cache [layer][position][row slot][3d] and work buffers."""
     needs_anc = True
+    takes_soft = True
 
     def __init__(self, dec, encs, enc_mask, k, max_len):
         self.dec, self.V = dec, dec.V
@@ -235,11 +253,16 @@ class TransformerSession:
     def reorder(self, row_parent, n_rows, identity):
         pass  # the KV cache is addressed through the ancestor table; nothing moves
 
-    def step(self, rows, n, t):
+    def step(self, rows, n, t, soft=None):
+        """Logits of the next token for rows 0..n-1 at position t.  ``soft`` ([>= n, Vp] fp32 token distributions,
+        see ``kernels.soft_embed``) replaces the lookup of ``rows.tok`` by the expected embedding."""
         dec, W = self.dec, self.dec.prepared()
         d, H = dec.d, dec.heads
         x, h, q, a, ff = self.x, self.h, self.q, self.a, self.ff
-        K.embed_posadd(rows.tok, W['emb'], W['pe'][t], self.scale, x, n)
+        if soft is None:
+            K.embed_posadd(rows.tok, W['emb'], W['pe'][t], self.scale, x, n)
+        else:
+            K.soft_embed(soft, dec.soft_embedding_matrix(), self.scale, W['pe'][t], x, n)
         for li, L in enumerate(W['layers']):
             K.layernorm(x, L['ln1'][0], L['ln1'][1], h, n)
             K.gemm(h, L['wqkv'], L['bqkv'], self.cache[li][t], n)
