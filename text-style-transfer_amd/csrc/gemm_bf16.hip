@@ -186,7 +186,255 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(const __bf16* __restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Fast path, K % 32 == 0: tiles of 32 k staged by LDS-DMA (global_load_lds, 16 bytes per lane), no staging
+// registers and no LDS store instructions.  One wave-instruction fills 16 tile rows of 64 bytes in lane order,
+// so the LDS image is plain [row][4 slots of 16 bytes]; bank conflicts of the fragment reads are avoided by a
+// permutation on the SOURCE side: slot s of row r holds k-chunk s ^ ((r >> 2) & 3), and the ds_read_b128 of
+// chunk c of row r goes to slot c ^ ((r >> 2) & 3) (the 16 lanes of a read group then touch 16 different
+// 16-byte bank slots).  NST stages in a ring, NST - 1 tiles in flight: the DMA of tile t + NST - 1 is issued
+// when tile t starts, a counted wait (all but the NST - 2 youngest tiles) plus one barrier per tile publishes
+// tile t + 1.  The fragment reads are inline assembly with explicit waits: the compiler orders every LDS read
+// it knows of behind ALL pending LDS-DMA, which would stall each tile on the DMA of the following ones.
+// The product is computed transposed, D = W_tile * A_tile^T: a lane then owns ONE output row (m = lane & 31)
+// and its 16 accumulator registers are 4 groups of 4 consecutive columns: bias and residual are 16-byte
+// accesses, fp32 results 16-byte stores; bf16 results are packed to 8 bytes per group and pass through a
+// wave-private LDS image so that 8 lanes store one 128-byte row segment.
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int DK = 32;   // k per tile of the DMA kernel
+
+template <int WVM, int WVN, int WTM, int WTN, int NST, bool OUT_BF16, bool HAS_RES, bool RELU>
+__global__ __launch_bounds__(64 * WVM * WVN) void gemm_bf16_dma_kernel(const __bf16* __restrict__ A, int64_t lda,
+                                                            const __bf16* __restrict__ W, int64_t ldw,
+                                                            const float* __restrict__ bias, const float* res, int64_t ldr,
+                                                            void* Cout, int64_t ldc, int M, int N, int K, int tiles_m,
+                                                            int tiles_n) {
+    // workgroup tile: WVM x WVN waves, each with WTM x WTN MFMA tiles of 32 x 32
+    constexpr int NWV = WVM * WVN, TM = 32 * WTM * WVM, TN = 32 * WTN * WVN;
+    constexpr int STAGE = (TM + TN) * 64;                // bytes of one stage: A rows then W rows, 64 bytes each
+    constexpr int OUT_LD = 16 + 64 * WTN;                // bytes per row of a wave's bf16 output image (+16: bank spread)
+    constexpr int IMG = 64 * OUT_LD;                     // the image holds 64 rows (two 32-row blocks) at a time
+    constexpr int SMEM = NST * STAGE > NWV * IMG ? NST * STAGE : NWV * IMG;
+    static_assert(TM % (16 * NWV) == 0 && TN % (16 * NWV) == 0 && WTM % 2 == 0, "tile shape");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[SMEM];
+
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
+    const int lb = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    const int per_group = GROUP_M * tiles_n;
+    const int first_m = (lb / per_group) * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (lb % per_group) % gsz;
+    const int tn = (lb % per_group) / gsz;
+    const int m0 = tm * TM, n0 = tn * TN;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WVN, wn = wave % WVN;
+
+    // DMA sources: wave w fills the 16-row blocks w, w + NWV, ... of the A rows and of the W rows; lane l of a
+    // block: row l >> 2, LDS slot l & 3, which takes k-chunk (l & 3) ^ ((row >> 2) & 3).  Rows beyond the matrix
+    // are clamped (their products are never stored).
+    constexpr int NA = TM / (16 * NWV), NW = TN / (16 * NWV);   // wave-instructions per wave and tile
+    const int srow = lane >> 2;
+    const __bf16* a_src[NA];
+    const __bf16* w_src[NW];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int row = (wave + NWV * j) * 16 + srow;
+        a_src[j] = A + (int64_t)min(m0 + row, M - 1) * lda + (((lane & 3) ^ ((row >> 2) & 3)) * 8);
+    }
+#pragma unroll
+    for (int j = 0; j < NW; ++j) {
+        const int row = (wave + NWV * j) * 16 + srow;
+        w_src[j] = W + (int64_t)min(n0 + row, N - 1) * ldw + (((lane & 3) ^ ((row >> 2) & 3)) * 8);
+    }
+    auto stage = [&](int st, int k0) {
+        unsigned char* base = smem + st * STAGE + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src[j] + k0), (lds_void_t*)(base + j * (1024 * NWV)), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NW; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(w_src[j] + k0), (lds_void_t*)(base + TM * 64 + j * (1024 * NWV)), 16, 0, 0);
+    };
+
+    // accumulators, transposed: acc[i][j][4 g + e] = C[m = 32 i + (lane & 31)][n = 32 j + 8 g + 4 (lane >> 5) + e]
+    f32x16 acc[WTM][WTN];
+    const int h = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < WTN; ++j) {
+        const int nb = n0 + wn * 32 * WTN + j * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (bias != nullptr) {
+                if (nb + 8 * g + 3 < N) {
+                    b4 = *reinterpret_cast<const float4*>(bias + nb + 8 * g);
+                } else {
+                    b4.x = bias[min(nb + 8 * g, N - 1)]; b4.y = bias[min(nb + 8 * g + 1, N - 1)];
+                    b4.z = bias[min(nb + 8 * g + 2, N - 1)]; b4.w = bias[min(nb + 8 * g + 3, N - 1)];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < WTM; ++i) {
+                acc[i][j][4 * g] = b4.x; acc[i][j][4 * g + 1] = b4.y; acc[i][j][4 * g + 2] = b4.z; acc[i][j][4 * g + 3] = b4.w;
+            }
+        }
+    }
+
+    const int nkt = K / DK;
+    // fragment read: row (lane & 31) of a 32-row block, chunk 2 ks + h -> slot (2 ks + h) ^ x, x = ((lane & 31) >> 2) & 3
+    const int x = ((lane & 31) >> 2) & 3;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const uint32_t a_off = lds_base + wm * 32 * WTM * 64 + (lane & 31) * 64;
+    const uint32_t w_off = lds_base + TM * 64 + wn * 32 * WTN * 64 + (lane & 31) * 64;
+    union Frag { u32x4 u; bf16x8 v; };
+    Frag fa[2][WTM], fw[2][WTN];   // fragments of the two k-steps of a tile
+    auto read_step = [&](int st, int ks) {
+        const uint32_t as = a_off + st * STAGE, ws = w_off + st * STAGE;
+        const uint32_t slot = ((2 * ks + h) ^ x) * 16;
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[ks][i].u) : "v"(as + i * 2048 + slot));
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(fw[ks][j].u) : "v"(ws + j * 2048 + slot));
+    };
+    auto mfma_step = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks][j].v, fa[ks][i].v, acc[i][j], 0, 0, 0);
+    };
+    auto lds_wait = [&]() {   // the scheduling barrier keeps the register-only MFMAs below the wait
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // An LDS-DMA is complete for OTHER waves only after the issuing wave has waited for it (vector-memory counter)
+    // and both have passed a barrier.  NDMA instructions per wave and tile; tiles complete in issue order.
+    // Schedule of tile kt (stage kt % NST):  wait for the k-step-0 fragments (read during the previous tile) | issue
+    // the k-step-1 reads | MFMAs of k-step 0 | wait: tile kt + 1 landed, own reads done | BARRIER (the MFMAs just
+    // issued keep the matrix pipe busy) | stage kt % NST is free: DMA of tile kt + NST into it | issue the k-step-0
+    // reads of tile kt + 1 | MFMAs of k-step 1.
+    constexpr int NDMA = NA + NW;
+#pragma unroll
+    for (int p = 0; p < NST; ++p)
+        if (p < nkt) stage(p, p * DK);
+    if (nkt >= NST) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NST - 1)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_step(0, 0);
+    int st = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int st_next = st + 1 == NST ? 0 : st + 1;
+        lds_wait();
+        read_step(st, 1);
+        mfma_step(0);
+        if (kt + NST - 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NST - 2)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        lds_wait();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + NST < nkt) stage(st, (kt + NST) * DK);
+        if (kt + 1 < nkt) read_step(st_next, 0);
+        mfma_step(1);
+        st = st_next;
+    }
+    __builtin_amdgcn_s_barrier();   // the epilogue reuses the stages: every wave must be past its last fragment read
+
+    // epilogue: per 32 x 32 block and register group g the lane has 4 consecutive columns of its row;
+    // two 32-row blocks (64 rows) at a time
+#pragma unroll
+    for (int i0 = 0; i0 < WTM; i0 += 2) {
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii) {
+            const int i = i0 + ii;
+            const int m = m0 + wm * 32 * WTM + i * 32 + (lane & 31);
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) {
+                const int nb = n0 + wn * 32 * WTN + j * 32 + 4 * h;
+                float v[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    v[r] = acc[i][j][r];
+                    if (RELU) v[r] = v[r] > 0.0f ? v[r] : 0.0f;
+                }
+                const bool row_ok = m < M;
+                const bool full = n0 + wn * 32 * WTN + j * 32 + 32 <= N;   // wave-uniform
+                if (HAS_RES && row_ok) {
+                    const float* rp = res + (int64_t)m * ldr + nb;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (full) {
+                            const float4 r4 = *reinterpret_cast<const float4*>(rp + 8 * g);
+                            v[4 * g] += r4.x; v[4 * g + 1] += r4.y; v[4 * g + 2] += r4.z; v[4 * g + 3] += r4.w;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (nb + 8 * g + e < N) v[4 * g + e] += rp[8 * g + e];
+                        }
+                    }
+                }
+                if (OUT_BF16) {
+                    // pack each group of 4 columns to 8 bytes and put it into the wave's LDS image [64 rows][32 WTN columns]
+                    unsigned char* img = smem + wave * IMG + (ii * 32 + (lane & 31)) * OUT_LD + (j * 32 + 4 * h) * 2;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                        union { bf16x4 b; uint2 u; } cv;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) cv.b[e] = (__bf16)v[4 * g + e];
+                        *reinterpret_cast<uint2*>(img + 16 * g) = cv.u;
+                    }
+                } else if (row_ok) {
+                    float* cp = reinterpret_cast<float*>(Cout) + (int64_t)m * ldc + nb;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        if (full) {
+                            *reinterpret_cast<float4*>(cp + 8 * g) = make_float4(v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (nb + 8 * g + e < N) cp[8 * g + e] = v[4 * g + e];
+                        }
+                    }
+                }
+            }
+        }
+        if (OUT_BF16) {
+            // the wave reads its image back by rows: LPR lanes x 16 bytes = the 32 WTN columns of a row
+            // (a wave only reads what it wrote itself: the compiler's LDS counter waits are all that is needed)
+            constexpr int LPR = 4 * WTN, RPP = 64 / LPR;    // lanes per row, rows per pass
+            const unsigned char* img = smem + wave * IMG;
+            const int c8 = (lane % LPR) * 8;
+            const int gcol = n0 + wn * 32 * WTN + c8;
+#pragma unroll
+            for (int p = 0; p < 64 / RPP; ++p) {
+                const int lrow = p * RPP + lane / LPR;
+                const int grow = m0 + wm * 32 * WTM + i0 * 32 + lrow;
+                if (grow >= M || gcol >= N) continue;
+                const uint4 o = *reinterpret_cast<const uint4*>(img + lrow * OUT_LD + c8 * 2);
+                __bf16* cp = reinterpret_cast<__bf16*>(Cout) + (int64_t)grow * ldc + gcol;
+                if (gcol + 8 <= N) {
+                    *reinterpret_cast<uint4*>(cp) = o;
+                } else {
+                    Chunk oc;
+                    oc.u = o;
+                    for (int e = 0; e < 8; ++e)
+                        if (gcol + e < N) cp[e] = oc.v[e];
+                }
+            }
+        }
+    }
+}
+
 }  // namespace
+
 
 extern "C" int tst_gemm_mfma_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                                   const float* res, int64_t ldr, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
@@ -201,14 +449,42 @@ extern "C" int tst_gemm_mfma_bf16(const void* A, int64_t lda, const void* W, int
                 "tst_gemm_mfma_bf16: res needs ldr >= N, ldr %% 4 == 0 and 16-byte alignment");
     TST_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_bf16: size");
     if (M == 0) return TST_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int variant = (out_bf16 ? 4 : 0) | (res != nullptr ? 2 : 0) | (act == 1 ? 1 : 0);
+    if (K % DK == 0 && tst_aligned16(bias)) {
+        // LDS-DMA kernel: 256 x 256 tiles (8 waves) when they give every CU a workgroup, else 128 x 128 (4 waves)
+        const bool big = ((M + 255) / 256) * ((N + 255) / 256) >= 256;
+        const int64_t tm = big ? (M + 255) / 256 : (M + 127) / 128, tn = big ? (N + 255) / 256 : (N + 127) / 128;
+        TST_REQUIRE(tm * tn < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_bf16: grid too large");
+        const dim3 g2((unsigned)(tm * tn));
+#define TST_BF16_DMA(OB, HR, RL)                                                                                      \
+    do {                                                                                                              \
+        if (big)                                                                                                      \
+            hipLaunchKernelGGL((gemm_bf16_dma_kernel<2, 4, 4, 2, 3, OB, HR, RL>), g2, dim3(512), 0, st, (const __bf16*)A, lda, \
+                               (const __bf16*)W, ldw, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, (int)tm, (int)tn); \
+        else                                                                                                          \
+            hipLaunchKernelGGL((gemm_bf16_dma_kernel<2, 2, 2, 2, 4, OB, HR, RL>), g2, dim3(256), 0, st, (const __bf16*)A, lda, \
+                               (const __bf16*)W, ldw, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, (int)tm, (int)tn); \
+    } while (0)
+        switch (variant) {
+            case 0: TST_BF16_DMA(false, false, false); break;
+            case 1: TST_BF16_DMA(false, false, true); break;
+            case 2: TST_BF16_DMA(false, true, false); break;
+            case 3: TST_BF16_DMA(false, true, true); break;
+            case 4: TST_BF16_DMA(true, false, false); break;
+            case 5: TST_BF16_DMA(true, false, true); break;
+            case 6: TST_BF16_DMA(true, true, false); break;
+            default: TST_BF16_DMA(true, true, true); break;
+        }
+#undef TST_BF16_DMA
+        return tst_after_launch("tst_gemm_mfma_bf16");
+    }
     const int64_t tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
     TST_REQUIRE(tiles_m * tiles_n < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_bf16: grid too large");
     const dim3 grid((unsigned)(tiles_m * tiles_n));
-    hipStream_t st = (hipStream_t)stream;
 #define TST_BF16_LAUNCH(OB, HR, RL)                                                                                 \
     hipLaunchKernelGGL((gemm_bf16_kernel<OB, HR, RL>), grid, dim3(256), 0, st, (const __bf16*)A, lda, (const __bf16*)W, \
                        ldw, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n)
-    const int variant = (out_bf16 ? 4 : 0) | (res != nullptr ? 2 : 0) | (act == 1 ? 1 : 0);
     switch (variant) {
         case 0: TST_BF16_LAUNCH(false, false, false); break;
         case 1: TST_BF16_LAUNCH(false, false, true); break;
