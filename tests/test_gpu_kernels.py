@@ -84,7 +84,8 @@ def test_embed_posadd_bit_exact(K):
     assert np.array_equal(out.cpu().numpy(), emb[tok])
 
 
-@pytest.mark.parametrize('d,heads,pos', [(256, 2, 0), (256, 2, 7), (256, 2, 49), (512, 8, 20), (64, 2, 5), (96, 1, 70)])
+@pytest.mark.parametrize('d,heads,pos', [(256, 2, 0), (256, 2, 7), (256, 2, 49), (512, 8, 20), (64, 2, 5), (96, 1, 70),
+                                         (512, 8, 0), (512, 8, 130), (256, 4, 63), (768, 12, 200)])
 def test_attn_self_step_bit_exact(K, d, heads, pos):
     r = rs(d + pos)
     R, slab, T = 21, 32, pos + 3
@@ -101,7 +102,8 @@ def test_attn_self_step_bit_exact(K, d, heads, pos):
     assert np.array_equal(out.cpu().numpy(), C.attention(q, Kc, Vc, None, None, pos + 1, heads))
 
 
-@pytest.mark.parametrize('d,heads,S,masked', [(256, 2, 12, True), (256, 2, 42, True), (512, 8, 9, False), (128, 1, 100, True)])
+@pytest.mark.parametrize('d,heads,S,masked', [(256, 2, 12, True), (256, 2, 42, True), (512, 8, 9, False), (128, 1, 100, True),
+                                            (256, 4, 70, True), (512, 8, 150, True)])
 def test_attn_cross_step_bit_exact(K, d, heads, S, masked):
     r = rs(d + S)
     B, R = 7, 26

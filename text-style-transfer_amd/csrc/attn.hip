@@ -171,12 +171,155 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
     }
 }
 
+__device__ __forceinline__ void st4(float* p, const float (&v)[4]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+}
+__device__ __forceinline__ void st4(__bf16* p, const float (&v)[4]) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 o;
+    o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+    *reinterpret_cast<bf16x4*>(p) = o;
+}
+
+// Heads of 64 elements: one wave per (row, 4 adjacent heads), 16 lanes per head, lane j of a head owns elements
+// 4 j .. 4 j + 3.  The 4 heads of a cache row are adjacent in memory, so every key or value access of the wave
+// is one contiguous 256-element segment (the one-wave-per-head kernel above would read a 64-element head with
+// one element per lane in its value pass).  Same arithmetic, in the same order, as that kernel: a score is the
+// 16-partial butterfly sum; the softmax sum keeps the 64 interleaved partials (position p -> partial p % 64),
+// four per lane, and folds them exactly as the 64-lane xor-butterfly would (32, 16 inside the lane; 8, 4, 2, 1
+// across the 16 lanes); the value sum runs over the positions in ascending order.
+template <typename T, bool SELF>
+__global__ __launch_bounds__(256) void attn_step_h64_kernel(
+    const T* __restrict__ base, int64_t slab_stride, const int32_t* __restrict__ anc, int64_t anc_ld,
+    const T* __restrict__ qbuf, const uint8_t* __restrict__ mask, const int32_t* __restrict__ sent, int n, T* __restrict__ out,
+    int64_t R, int d, int heads, float scale) {
+    __shared__ float sc[4][4][MAXP];   // [wave][head of the group][position]: score, then softmax weight
+    __shared__ int slot[4][MAXP];      // SELF: cache row of every position; else: the list of unmasked positions
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int hgroups = heads >> 2;
+    int64_t gw = (int64_t)blockIdx.x * 4 + w;
+    const int64_t total = R * hgroups;
+    if (gw >= total) gw = total - 1;   // surplus waves redo the last item: same values, no early exit before barriers
+    const int64_t r = gw / hgroups;
+    const int g = lane >> 4, j = lane & 15;
+    const int eoff = ((int)(gw - r * hgroups) * 4 + g) * 64 + 4 * j;   // this lane's 4 elements inside a row of d
+    const int pos = n - 1;
+
+    const T* qp;
+    int64_t ent = 0;
+    int nl;
+    if (SELF) {
+        for (int p = lane; p < n; p += 64) slot[w][p] = (p < pos) ? anc[r * anc_ld + p] : (int)r;
+        qp = base + (int64_t)pos * slab_stride + r * 3 * d + eoff;
+        nl = n;
+    } else {
+        ent = sent[r];
+        qp = qbuf + r * d + eoff;
+        nl = 0;
+        for (int p0 = 0; p0 < n; p0 += 64) {
+            const int p = p0 + lane;
+            const bool live = p < n && (mask == nullptr || mask[ent * n + p] != 0);
+            const unsigned long long bal = __ballot(live);
+            if (live) slot[w][nl + __popcll(bal & ((1ull << lane) - 1ull))] = p;
+            else if (p < n) { sc[w][0][p] = -INFINITY; sc[w][1][p] = -INFINITY; sc[w][2][p] = -INFINITY; sc[w][3][p] = -INFINITY; }
+            nl += __popcll(bal);
+        }
+    }
+    const float4 qv = ld4(qp);
+    __syncthreads();
+
+    auto krow = [&](int i) -> const T* {   // this lane's 4 key elements of the i-th live position; values d further
+        if (SELF) return base + (int64_t)i * slab_stride + (int64_t)slot[w][i] * 3 * d + d + eoff;
+        return base + (ent * n + slot[w][i]) * 2 * (int64_t)d + eoff;
+    };
+
+    for (int i0 = 0; i0 < nl; i0 += 8) {   // 8 positions in flight
+        float part[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const float4 kv = ld4(krow(min(i0 + u, nl - 1)));
+            float acc = 0.0f;
+            acc = __builtin_fmaf(qv.x, kv.x, acc);
+            acc = __builtin_fmaf(qv.y, kv.y, acc);
+            acc = __builtin_fmaf(qv.z, kv.z, acc);
+            acc = __builtin_fmaf(qv.w, kv.w, acc);
+            part[u] = acc;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = i0 + u;
+            const float tot = group16_sum_butterfly(part[u]);
+            if (j == 0 && i < nl) sc[w][g][SELF ? i : slot[w][i]] = tot * scale;
+        }
+    }
+    __syncthreads();
+
+    // softmax of head g: this lane holds the positions j + 16 q + 64 i, i.e. partials j + 16 q of the 64
+    float s[MAXP / 64][4];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < MAXP / 64; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = j + 16 * q + 64 * i;
+            s[i][q] = p < n ? sc[w][g][p] : -INFINITY;
+            m = fmaxf(m, s[i][q]);
+        }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int i = 0; i < MAXP / 64; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = j + 16 * q + 64 * i;
+            const float e = p < n ? d_exp_le0(s[i][q] - m) : 0.0f;
+            s[i][q] = e;
+            part[q] = part[q] + e;
+        }
+    const float sum = group16_sum_butterfly((part[0] + part[2]) + (part[1] + part[3]));
+#pragma unroll
+    for (int i = 0; i < MAXP / 64; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int p = j + 16 * q + 64 * i;
+            if (p < n) sc[w][g][p] = s[i][q] / sum;
+        }
+    __syncthreads();
+
+    float acc[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+    for (int i0 = 0; i0 < nl; i0 += 8) {
+        float wgt[8];
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int i = min(i0 + u, nl - 1);
+            wgt[u] = i0 + u < nl ? sc[w][g][SELF ? i : slot[w][i]] : 0.0f;   // beyond the list: weight 0, no effect
+            v[u] = ld4(krow(i) + d);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            acc[0] = __builtin_fmaf(wgt[u], v[u].x, acc[0]);
+            acc[1] = __builtin_fmaf(wgt[u], v[u].y, acc[1]);
+            acc[2] = __builtin_fmaf(wgt[u], v[u].z, acc[2]);
+            acc[3] = __builtin_fmaf(wgt[u], v[u].w, acc[3]);
+        }
+    }
+    st4(out + r * d + eoff, acc);
+}
+
 template <typename T, bool SELF>
 int launch_attn(const T* base, int64_t slab_stride, const int32_t* anc, int64_t anc_ld, const T* q,
                 const uint8_t* mask, const int32_t* sent, int64_t n, T* out, int64_t R, int64_t d, int64_t heads,
                 hipStream_t stream, const char* name) {
     const int64_t dh = d / heads;
     const float scale = (float)(1.0 / sqrt((double)dh));  // rounded once, from the double-precision value
+    if (dh == 64 && heads % 4 == 0) {
+        const unsigned grid4 = (unsigned)((R * (heads / 4) + 3) / 4);
+        hipLaunchKernelGGL((attn_step_h64_kernel<T, SELF>), dim3(grid4), dim3(256), 0, stream, base, slab_stride, anc, anc_ld, q,
+                           mask, sent, (int)n, out, R, (int)d, (int)heads, scale);
+        return tst_after_launch(name);
+    }
     const unsigned grid = (unsigned)((R * heads + 3) / 4);
     const int nch = (int)((dh + 63) / 64);
     const int vec = (dh % 256 == 0) ? 4 : (dh % 128 == 0) ? 2 : 1;
