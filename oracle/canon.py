@@ -380,6 +380,34 @@ class CanonGRUDecoder:
         return _GRUSession(self, np.repeat(z, rows_per_sentence, axis=1))
 
 
+def _gru_weights(sd, prefix='gru.'):
+    return dict(wih=np.ascontiguousarray(_np(sd[prefix + 'weight_ih_l0']).T), bih=_np(sd[prefix + 'bias_ih_l0']),
+                whh=np.ascontiguousarray(_np(sd[prefix + 'weight_hh_l0']).T), bhh=_np(sd[prefix + 'bias_hh_l0']))
+
+
+def rnn_encoder(torch_module, x):
+    """``oracle.torch_ref.RNNEncoder`` in canonical arithmetic: final state of the GRU over all positions of x [B, T]."""
+    sd = torch_module.state_dict()
+    c, emb = _gru_weights(sd), _np(sd['embed.weight'])
+    x = np.asarray(x)
+    h = np.zeros((x.shape[0], c['whh'].shape[0]), np.float32)
+    for t in range(x.shape[1]):
+        gi = gemm(embed_posadd(x[:, t].astype(np.int32), emb, None, 1.0), c['wih'], c['bih'])
+        h = gru_cell(gi, gemm(h, c['whh'], c['bhh']), h)
+    return h
+
+
+def generator(torch_module, z):
+    """``oracle.torch_ref.Generator`` in canonical arithmetic."""
+    c = _gru_weights(torch_module.state_dict())
+    z = np.ascontiguousarray(np.asarray(z, np.float32))
+    gi = gemm(z, c['wih'], c['bih'])
+    h = z.copy()
+    for _ in range(torch_module.n_steps):
+        h = gru_cell(gi, gemm(h, c['whh'], c['bhh']), h)
+    return h
+
+
 class _GRUSession:
     def __init__(self, m, h):
         self.m, self.h = m, [np.ascontiguousarray(h[i]) for i in range(h.shape[0])]

@@ -322,6 +322,20 @@ class RNNEncoder(nn.Module):
         return self.gru(self.embed(x))[1].squeeze(0)
 
 
+class Generator(nn.Module):
+    """Restatement of ``Generator`` at ``/root/reference/src/trainers/cyclegan_trainer.py:337-348``: a GRU that is fed
+    ``n_steps`` copies of z, starts at z and returns its final state."""
+
+    def __init__(self, size, n_steps):
+        super().__init__()
+        self.n_steps = n_steps
+        self.gru = nn.GRU(size, size, batch_first=True)
+
+    def forward(self, z):
+        x = z.unsqueeze(1).repeat(1, self.n_steps, 1)
+        return self.gru(x, z.unsqueeze(0))[1].squeeze(0)
+
+
 class RNNLM(nn.Module):
     """Multi-layer GRU language model with carried state ``z [n_layers, B, size]``; constructor as at
     ``/root/reference/src/prod/dialog_model.py:49``: ``RNNLM(size, vocab, n_layers=...)``."""

@@ -250,3 +250,31 @@ def test_sampling_decode_matches_oracle_draw_for_draw(T):
     torch.manual_seed(5)
     b = seqs_of(state_for(T, fx, model, vocab, sample_type='sample', max_len=20).inference())
     assert a == b                                   # torch.manual_seed governs the default seed
+
+
+def test_gru_pre_decode_pass_bit_exact_and_feeds_the_loop(T):
+    """RNNEncoder -> Generator -> simple_inference, the call chain of
+    /root/reference/src/trainers/cyclegan_trainer.py:321-332: encoder and generator outputs equal the canonical oracle
+    bit for bit and stock PyTorch within the fp32 tolerance; the decoded tokens equal the oracle's."""
+    from oracle import torch_ref as R
+    vocab_t = R.synthetic_vocab(60, extra=('|',))
+    enc_t = R.synthetic_init(R.RNNEncoder(64, 64, vocab_t), seed=5)
+    gen_t = R.synthetic_init(R.Generator(64, 3), seed=6)
+    dec_t = R.synthetic_init(R.RNNDecoder(64, 64, vocab_t), vocab_t.stoi['|'], 1.0, 2.0, seed=7)
+    vocab = T.Vocab.synthetic(60, extra=('|',))
+    enc, gen, dec = T.RNNEncoder(64, 64, vocab, 0.1, noise=0.2), T.Generator(64, 3), T.RNNDecoder(64, 64, vocab)
+    enc.load_state_dict(enc_t.state_dict()); gen.load_state_dict(gen_t.state_dict()); dec.load_state_dict(dec_t.state_dict())
+    x = np.random.RandomState(3).randint(0, 60, size=(37, 13))
+    z = enc(torch.from_numpy(x).cuda())
+    assert np.array_equal(z.cpu().numpy(), C.rnn_encoder(enc_t, x))
+    z2 = gen(z)
+    assert np.array_equal(z2.cpu().numpy(), C.generator(gen_t, z.cpu().numpy()))
+    with torch.no_grad():
+        zt = enc_t(torch.from_numpy(x))
+        ok, err = logits_close(z.cpu().numpy(), zt.numpy())
+        assert ok, err
+        ok, err = logits_close(z2.cpu().numpy(), gen_t(zt).numpy())
+        assert ok, err
+    out = T.simple_inference(dec, z2, vocab, max_len=15, eos_token='|')
+    want = C.greedy_decode(C.CanonGRUDecoder(dec_t).session(z2.cpu().numpy()), 37, 15, vocab.stoi['<bos>'], vocab.stoi['|'])[0]
+    assert out == want

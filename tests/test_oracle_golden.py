@@ -155,3 +155,20 @@ def test_gumbel_restatement_matches_reference_fixture(name):
     for i, o in enumerate(out):
         assert tuple(o.shape) == (1, fx['lens'][i] * V)
         assert np.array_equal(o.reshape(-1, V).numpy(), fx['dists'][i, :fx['lens'][i]])
+
+
+def test_canonical_rnn_encoder_and_generator_close_to_torch():
+    """The pre-decode pass of the GRU path (/root/reference/src/trainers/cyclegan_trainer.py:321-327,337-348): the
+    canonical-arithmetic oracle against stock PyTorch on the specification modules."""
+    vocab = R.synthetic_vocab(50)
+    enc = R.synthetic_init(R.RNNEncoder(32, 64, vocab), seed=5)
+    gen = R.synthetic_init(R.Generator(64, 3), seed=6)
+    x = torch.from_numpy(np.random.RandomState(2).randint(0, 50, size=(7, 11)))
+    with torch.no_grad():
+        z = enc(x)
+        z2 = gen(z)
+    cz = C.rnn_encoder(enc, x.numpy())
+    ok, err = logits_close(cz, z.numpy())
+    assert ok, err
+    ok, err = logits_close(C.generator(gen, z.numpy()), z2.numpy())
+    assert ok, err

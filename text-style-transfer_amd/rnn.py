@@ -4,6 +4,9 @@ Call surfaces as used by the reference: ``RNNDecoder(emb_size, hid_size, vocab, 
 ``decoder(z [B,H], x [B,T]) -> [B,T,V]`` (``/root/reference/src/trainers/cyclegan_trainer.py:64``,
 ``/root/reference/src/inference.py:170-177``) and ``RNNLM(size, vocab, n_layers)`` with
 ``lm(z [n_layers,B,H], x, return_z=True) -> (logits, z')`` (``/root/reference/src/prod/dialog_model.py:49,108-120``).
+Before the loop (``/root/reference/src/trainers/cyclegan_trainer.py:321-332``): ``RNNEncoder(emb, hid, vocab, dropword_p,
+noise=...)`` with ``encoder(x [B,T]) -> z [B,H]`` (``:63``) and ``Generator(size, n_steps)`` with ``gen(z) -> z'``
+(``:337-348``: a GRU fed n_steps copies of z, started at z).
 Architecture (this build's own, the reference's model source is an absent submodule): embedding ->
 n_layers GRU (PyTorch gate order and formula) -> linear to raw logits.  The decode loop carries the hidden
 state instead of re-running the prefix (``/root/reference/src/inference.py:132`` re-runs it).
@@ -133,3 +136,85 @@ class GRUSession:
             x = self.h[l]
         K.gemm(x, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
         return self.logits
+
+
+class RNNEncoder(HipModule):
+    """``RNNEncoder(emb_size, hid_size, vocab, dropword_p, noise=...)``; ``encoder(x [B, T] ids) -> z [B, H]``, the
+    final state of a one-layer GRU started at zero and run over all T positions (padding included, nothing is
+    packed).  Inference only: ``dropword_p`` and ``noise`` act in training and are ignored.  The input products of
+    all positions are one GEMM ([B * T, E] x [E, 3H]); the loop over positions does the recurrent product and the
+    gate update."""
+
+    def __init__(self, emb_size, hid_size, vocab, dropword_p=0.0, noise=0.0, device='cuda'):
+        super().__init__(device)
+        if emb_size % 4 or hid_size % 4:
+            raise ValueError('embedding and hidden sizes must be multiples of 4')
+        self.vocab, self.E, self.H, self.V = vocab, emb_size, hid_size, len(vocab)
+        s = 1.0 / math.sqrt(hid_size)
+        self._add('embed.weight', (self.V, emb_size), std=1.0)
+        self._add('gru.weight_ih_l0', (3 * hid_size, emb_size), std=s)
+        self._add('gru.weight_hh_l0', (3 * hid_size, hid_size), std=s)
+        self._add('gru.bias_ih_l0', (3 * hid_size,), std=s)
+        self._add('gru.bias_hh_l0', (3 * hid_size,), std=s)
+
+    def prepared(self):
+        if self._prepared is None:
+            P = self._params
+            self._prepared = dict(emb=P['embed.weight'].contiguous(), wih=_t(P['gru.weight_ih_l0']), bih=P['gru.bias_ih_l0'],
+                                  whh=_t(P['gru.weight_hh_l0']), bhh=P['gru.bias_hh_l0'])
+        return self._prepared
+
+    def __call__(self, x):
+        W = self.prepared()
+        B, T = x.shape
+        dev = self.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        tok = x.to(device=dev, dtype=torch.int32).t().contiguous().view(-1)      # position-major: rows t * B + b
+        emb = torch.empty((T * B, self.E), **f32)
+        K.embed_posadd(tok, W['emb'], None, 1.0, emb, T * B)
+        gi = torch.empty((T * B, 3 * self.H), **f32)
+        K.gemm(emb, W['wih'], W['bih'], gi, T * B)
+        h = torch.zeros((B, self.H), **f32)
+        gh = torch.empty((B, 3 * self.H), **f32)
+        for t in range(T):
+            K.gemm(h, W['whh'], W['bhh'], gh, B)
+            K.gru_cell_step(gi[t * B:(t + 1) * B], gh, h, h, B)
+        return h
+
+
+class Generator(HipModule):
+    """``Generator(size, n_steps)``; ``gen(z [B, size]) -> [B, size]``: a one-layer GRU whose input is z at every one
+    of the n_steps steps and whose initial state is z (``/root/reference/src/trainers/cyclegan_trainer.py:337-348``).
+    The input product is therefore the same at every step and is computed once."""
+
+    def __init__(self, size, n_steps, device='cuda'):
+        super().__init__(device)
+        if size % 4:
+            raise ValueError('size must be a multiple of 4')
+        self.size, self.n_steps = size, n_steps
+        s = 1.0 / math.sqrt(size)
+        self._add('gru.weight_ih_l0', (3 * size, size), std=s)
+        self._add('gru.weight_hh_l0', (3 * size, size), std=s)
+        self._add('gru.bias_ih_l0', (3 * size,), std=s)
+        self._add('gru.bias_hh_l0', (3 * size,), std=s)
+
+    def prepared(self):
+        if self._prepared is None:
+            P = self._params
+            self._prepared = dict(wih=_t(P['gru.weight_ih_l0']), bih=P['gru.bias_ih_l0'], whh=_t(P['gru.weight_hh_l0']),
+                                  bhh=P['gru.bias_hh_l0'])
+        return self._prepared
+
+    def __call__(self, z):
+        W = self.prepared()
+        z = z.to(device=self.device, dtype=torch.float32).contiguous()
+        B = z.shape[0]
+        f32 = dict(dtype=torch.float32, device=self.device)
+        gi = torch.empty((B, 3 * self.size), **f32)
+        gh = torch.empty((B, 3 * self.size), **f32)
+        K.gemm(z, W['wih'], W['bih'], gi, B)
+        h = z.clone()
+        for _ in range(self.n_steps):
+            K.gemm(h, W['whh'], W['bhh'], gh, B)
+            K.gru_cell_step(gi, gh, h, h, B)
+        return h

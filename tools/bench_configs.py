@@ -55,13 +55,13 @@ def cfg3(n_sent, bias=None):
                                                 'beam_size': beam}), n_sent)
 
 
-def cfg4(n_sent, bias=None):
+def cfg4(n_sent, bias=None, dtypes=('bf16', 'fp32')):
     dev = torch.device('cuda', 0)
     V = 32000
     vocab = tst_amd.Vocab.synthetic(V)
     hp = dict(model_size=512, n_layers=6, n_heads=8, d_ff=2048, pe_max_len=64)
     z = (0.3 * torch.randn((n_sent, 512), generator=torch.Generator().manual_seed(1238))).to(dev)
-    for dtype in ('bf16', 'fp32'):
+    for dtype in dtypes:
         lm = tst_amd.TransformerLM(tst_amd.HP(hp), vocab, device=dev, dtype=dtype)
         lm.load_state_dict(synthetic.synthetic_state_dict(lm, 3, 5.0 if bias is None else bias, 2.0, seed=42))
         run('cfg4 TransformerLM d=512 L=6 V=32000 beam=8 %s max_len=50' % dtype,
@@ -75,9 +75,10 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('which', nargs='?', default='all')
     ap.add_argument('--sentences', type=int, default=8192)
+    ap.add_argument('--dtype', default=None, help='cfg4: only this dtype (bf16 or fp32)')
     ap.add_argument('--eos-bias', type=float, default=None, help='override the calibrated EOS bias (calibration runs)')
     a = ap.parse_args()
     if a.which in ('cfg3', 'all'):
         cfg3(a.sentences, a.eos_bias)
     if a.which in ('cfg4', 'all'):
-        cfg4(a.sentences, a.eos_bias)
+        cfg4(a.sentences, a.eos_bias, ('bf16', 'fp32') if a.dtype is None else (a.dtype,))
