@@ -117,6 +117,13 @@ int tst_argmax_rows_f32(const float* logits, int64_t ld, int64_t R, int64_t V, i
 int tst_gumbel_softmax_f32(const float* logits, int64_t ld, int64_t R, int64_t V, const float* u, int64_t ldu,
                            float temperature, float* out, int64_t ldo, void* stream);
 
+/* out[r][v] = log(sum_i weights[i] * softmax(logits_i[r][:])[v]), logits_i = logits + i * model_stride, i < n_models <= 8:
+ * WeightedLMEnsemble.weight at /root/reference/src/prod/throwaway_models.py:32-36 (softmax of every member's logits,
+ * weighted sum, log).  weights is a device array of n_models floats.  out may be one of the members' buffers only if
+ * it is the LAST one (a row is read completely before it is written, but members are read in ascending order). */
+int tst_mix_logprobs_f32(const float* logits, int64_t model_stride, int64_t ld, int64_t n_models, const float* weights,
+                         int64_t R, int64_t V, float* out, int64_t ldo, void* stream);
+
 /* tok[r] ~ Categorical(logits = logits[r] / temperature): Categorical(...).sample() at
  * /root/reference/src/inference.py:147, drawn by the Gumbel-max trick, argmax_v (x_v / temperature - log(-log u_v)),
  * with u_v in (0,1) from a counter-based hash of (seed, step, sent[r], v), so a sentence's draws do not depend on

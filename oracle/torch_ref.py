@@ -352,6 +352,28 @@ class RNNLM(nn.Module):
         return (logits, z_new) if return_z else logits
 
 
+class WeightedLMEnsemble(nn.Module):
+    """Restatement of ``WeightedLMEnsemble`` at ``/root/reference/src/prod/throwaway_models.py:9-36``: every member gets
+    its own state ``zs[i]``; the prediction is log(sum_i w_i * softmax(logits_i))."""
+
+    def __init__(self, models, weights):
+        super().__init__()
+        assert len(models) == len(weights)
+        assert sum(weights) == 1
+        self.models = nn.ModuleList(models)
+        self.weights = weights
+
+    def forward(self, zs, x, return_z=False):
+        if return_z:
+            results = [m(z, x, return_z) for m, z in zip(self.models, zs)]
+            return self.weight([r[0] for r in results]), torch.stack([r[1] for r in results])
+        return self.weight([m(z, x) for m, z in zip(self.models, zs)])
+
+    def weight(self, logits):
+        probs = [F.softmax(l, dim=2) for l in logits]
+        return sum([w * p for w, p in zip(self.weights, probs)]).log()
+
+
 def synthetic_init(module, eos_idx=None, eos_bias=0.0, out_scale=1.0, seed=42):
     """Deterministic random init used by fixtures, tests and the benchmark.
 

@@ -198,6 +198,32 @@ def tlm_case(InferenceState, name, hp, V, B, max_len, eos_bias, out_scale, seed,
     save(name, config, {'z': z.numpy()}, seqs, rec, finished_lens_of(seqs, max_len))
 
 
+def ensemble_members(V, H, n_layers, seeds, eos_bias, out_scale):
+    vocab = R.synthetic_vocab(V, extra=('|',))
+    return vocab, [R.synthetic_init(R.RNNLM(H, vocab, n_layers), vocab.stoi['|'], eos_bias, out_scale, seed=sd) for sd in seeds]
+
+
+def ensemble_case(InferenceState, name, V, H, n_layers, B, max_len, weights, seeds, eos_bias, out_scale, seed, keep=6):
+    """The REAL ``WeightedLMEnsemble`` (/root/reference/src/prod/throwaway_models.py:9-36) over two GRU language models,
+    driven by the real loop in the stateful mode of /root/reference/src/prod/dialog_model.py:103,108-120
+    (``inputs_batch_dim`` 2), with greedy selection (sampling there has no fixed output)."""
+    from src.prod.throwaway_models import WeightedLMEnsemble
+    rs = np.random.RandomState(seed)
+    vocab, members = ensemble_members(V, H, n_layers, seeds, eos_bias, out_scale)
+    ens = WeightedLMEnsemble(members, weights).eval()
+    zs = torch.from_numpy(rs.standard_normal((len(members), n_layers, B, H)).astype(np.float32))
+    rec = Recorder(ens, keep)
+    with torch.no_grad():
+        seqs = InferenceState({'model': rec, 'inputs': zs, 'vocab': vocab, 'max_len': max_len, 'bos_token': '|',
+                               'eos_token': '|', 'substitute_inputs': True, 'inputs_batch_dim': 2,
+                               'kwargs': {'return_z': True}}).inference()
+    seqs = [s.tolist() for s in seqs]
+    config = dict(kind='ensemble', V=V, H=H, n_layers=n_layers, weights=weights, member_seeds=seeds, eos_bias=eos_bias,
+                  out_scale=out_scale, max_len=max_len, data_seed=seed,
+                  source='reference src/inference.py (stateful) + src/prod/throwaway_models.py WeightedLMEnsemble')
+    save(name, config, {'zs': zs.numpy()}, seqs, rec, finished_lens_of(seqs, max_len))
+
+
 def gumbel_case(InferenceState, name, kind, V, B, max_len, temperature, eos_bias, out_scale, seed, noise_seed, keep=4):
     """The gumbel branch of the reference loop (``/root/reference/src/inference.py:83-88,104-105,136-138``,
     ``/root/reference/src/utils/gumbel.py:11-21``): it runs when the caller provides ``active_seqs`` as
@@ -348,6 +374,8 @@ def main():
     stateful_case(InferenceState, 'rnnlm_stateful', H=64, V=50, n_layers=2, B=4, max_len=14, eos_bias=1.0,
                   out_scale=2.0, seed=105)
     gumbel_op_case()
+    ensemble_case(InferenceState, 'ensemble_rnnlm', V=50, H=32, n_layers=2, B=5, max_len=12, weights=[0.25, 0.75],
+                  seeds=[42, 43], eos_bias=1.0, out_scale=2.0, seed=109)
     gumbel_case(InferenceState, 'gumbel_gru', 'gru', V=40, B=5, max_len=10, temperature=0.7, eos_bias=1.0, out_scale=2.0,
                 seed=107, noise_seed=7)
     gumbel_case(InferenceState, 'gumbel_tfm', 'tfm', V=64, B=4, max_len=9, temperature=1.0, eos_bias=1.5, out_scale=2.0,

@@ -278,3 +278,41 @@ def test_gru_pre_decode_pass_bit_exact_and_feeds_the_loop(T):
     out = T.simple_inference(dec, z2, vocab, max_len=15, eos_token='|')
     want = C.greedy_decode(C.CanonGRUDecoder(dec_t).session(z2.cpu().numpy()), 37, 15, vocab.stoi['<bos>'], vocab.stoi['|'])[0]
     assert out == want
+
+
+def test_weighted_lm_ensemble_matches_reference_fixture(T):
+    """WeightedLMEnsemble (/root/reference/src/prod/throwaway_models.py:9-36) of two HIP-backed GRU language models in
+    the stateful mode of /root/reference/src/prod/dialog_model.py:103,108-120: tokens identical to the real class under
+    the real loop, log-mixtures within the fp32 tolerance; teacher-forced call against the torch restatement."""
+    from oracle import torch_ref as R
+    from test_oracle_golden import ensemble_torch_model
+    fx = load_fixture('ensemble_rnnlm')
+    cfg = fx['config']
+    ens_t, members_t, _ = ensemble_torch_model(cfg)
+    vocab = T.Vocab.synthetic(cfg['V'], extra=('|',))
+    members = []
+    for mt in members_t:
+        m = T.RNNLM(cfg['H'], vocab, cfg['n_layers'])
+        m.load_state_dict(mt.state_dict())
+        members.append(m)
+    ens = T.WeightedLMEnsemble(members, cfg['weights'])
+    zs = torch.from_numpy(fx['zs']).cuda()
+    st = T.InferenceState({'model': ens, 'inputs': zs, 'vocab': vocab, 'max_len': cfg['max_len'], 'bos_token': '|',
+                           'eos_token': '|', 'substitute_inputs': True, 'inputs_batch_dim': 2, 'kwargs': {'return_z': True}})
+    out = st.inference(keep_logits=6)
+    assert seqs_of(out) == fx['seqs']
+    for i in range(sum(1 for k in fx if k.startswith('logits_s'))):
+        lg, sent, _ = st.loop.kept[i]
+        assert np.array_equal(sent.cpu().numpy(), fx['rows_s%d' % i])
+        ok, err = logits_close(lg.cpu().numpy(), fx['logits_s%d' % i])
+        assert ok, (i, err)
+    x = torch.from_numpy(np.random.RandomState(4).randint(0, cfg['V'], size=(5, 7)))
+    with torch.no_grad():
+        want, want_z = ens_t(torch.from_numpy(fx['zs']), x, return_z=True)
+    got, got_z = ens(zs, x.cuda(), return_z=True)
+    ok, err = logits_close(got.cpu().numpy(), want.numpy())
+    assert ok, err
+    ok, err = logits_close(got_z.cpu().numpy(), want_z.numpy())
+    assert ok, err
+    with pytest.raises(AssertionError):
+        T.WeightedLMEnsemble(members, [0.5, 0.6])

@@ -172,3 +172,25 @@ def test_canonical_rnn_encoder_and_generator_close_to_torch():
     assert ok, err
     ok, err = logits_close(C.generator(gen, z.numpy()), z2.numpy())
     assert ok, err
+
+
+def ensemble_torch_model(cfg):
+    vocab = R.synthetic_vocab(cfg['V'], extra=('|',))
+    members = [R.synthetic_init(R.RNNLM(cfg['H'], vocab, cfg['n_layers']), vocab.stoi['|'], cfg['eos_bias'], cfg['out_scale'], seed=sd)
+               for sd in cfg['member_seeds']]
+    return R.WeightedLMEnsemble(members, cfg['weights']).eval(), members, vocab
+
+
+def test_ensemble_restatement_matches_reference_fixture():
+    """``oracle.torch_ref.WeightedLMEnsemble`` under the restated loop against the real class under the real loop."""
+    fx = load_fixture('ensemble_rnnlm')
+    cfg = fx['config']
+    ens, _, vocab = ensemble_torch_model(cfg)
+    st = R.RefInferenceState({'model': ens, 'inputs': torch.from_numpy(fx['zs']), 'vocab': vocab, 'max_len': cfg['max_len'],
+                              'bos_token': '|', 'eos_token': '|', 'substitute_inputs': True, 'inputs_batch_dim': 2,
+                              'kwargs': {'return_z': True}})
+    seqs = [s.tolist() for s in st.inference(keep_logits=KEEP)]
+    assert seqs == fx['seqs']
+    for i in range(sum(1 for k in fx if k.startswith('logits_s'))):
+        assert np.array_equal(st.step_rows[i].numpy(), fx['rows_s%d' % i])
+        assert np.array_equal(st.step_logits[i].numpy(), fx['logits_s%d' % i])

@@ -35,6 +35,7 @@ _PROTOS = {
     'tst_gather_rows_f32': ([c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_argmax_rows_f32': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_vp], c_int),
     'tst_gumbel_softmax_f32': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp, c_i64, c_vp], c_int),
+    'tst_mix_logprobs_f32': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp], c_int),
     'tst_sample_rows_f32': ([c_vp, c_i64, c_i64, c_i64, c_f32, ctypes.c_uint32, ctypes.c_uint32, c_vp, c_vp, c_vp], c_int),
     'tst_logsoftmax_topk_f32': ([c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp], c_int),
     'tst_layernorm_f32_bf16': ([c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_vp], c_int),

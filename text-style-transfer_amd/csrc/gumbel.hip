@@ -1,4 +1,5 @@
-// Soft ("gumbel") decoding step: out = softmax((softmax(logits) + G) / temperature) per row, with
+// Row-wise operations on token distributions: the soft ("gumbel") decoding step and the mixture of an ensemble.
+// Soft decoding step: out = softmax((softmax(logits) + G) / temperature) per row, with
 // G = -log(-log(U + 1e-20) + 1e-20) from caller-provided uniform draws U.  One workgroup per row; the row
 // is walked five times (max, sum, noisy scores + their max, exponentials + their sum, normalisation) with
 // coalesced 4-byte accesses; after the first walk it is served from L2.  fp32 throughout, the same
@@ -58,7 +59,50 @@ __global__ __launch_bounds__(256) void gumbel_softmax_kernel(const float* __rest
     for (int i = t; i < V; i += 256) yr[i] = yr[i] / ys;
 }
 
+// out[v] = log(sum_i w[i] * softmax(x_i)[v]) for n_models logit rows x_i of one batch row: a weighted mixture of the
+// members' distributions, returned as log-probabilities.  One workgroup per batch row; first the max and the sum of
+// exponentials of every member (kept in LDS), then one pass that mixes, members in ascending order.
+constexpr int MIX_MAX = 8;
+
+__global__ __launch_bounds__(256) void mix_logprobs_kernel(const float* __restrict__ x, int64_t model_stride, int64_t ld,
+                                                           int n_models, const float* __restrict__ w, int V,
+                                                           float* __restrict__ out, int64_t ldo) {
+    __shared__ float red[4];
+    __shared__ float mm[MIX_MAX], ss[MIX_MAX], ww[MIX_MAX];
+    const int t = threadIdx.x;
+    const float* xr = x + (int64_t)blockIdx.x * ld;
+    for (int i = 0; i < n_models; ++i) {
+        const float* xi = xr + i * model_stride;
+        float m = -INFINITY;
+        for (int v = t; v < V; v += 256) m = fmaxf(m, xi[v]);
+        m = block_max(m, red);
+        float s = 0.0f;
+        for (int v = t; v < V; v += 256) s = s + d_exp_le0(xi[v] - m);
+        s = block_sum(s, red);
+        if (t == 0) { mm[i] = m; ss[i] = s; ww[i] = w[i]; }
+    }
+    __syncthreads();
+    float* yr = out + (int64_t)blockIdx.x * ldo;
+    for (int v = t; v < V; v += 256) {
+        float acc = 0.0f;
+        for (int i = 0; i < n_models; ++i) acc = acc + ww[i] * (d_exp_le0(xr[i * model_stride + v] - mm[i]) / ss[i]);
+        yr[v] = d_log(acc);
+    }
+}
+
 }  // namespace
+
+extern "C" int tst_mix_logprobs_f32(const float* logits, int64_t model_stride, int64_t ld, int64_t n_models,
+                                    const float* weights, int64_t R, int64_t V, float* out, int64_t ldo, void* stream) {
+    TST_REQUIRE(logits && weights && out, TST_ERR_ARG, "tst_mix_logprobs_f32: null pointer");
+    TST_REQUIRE(R >= 0 && V > 0 && ld >= V && ldo >= V && V < (1ll << 30) && R < (1ll << 31) && model_stride >= 0, TST_ERR_ARG,
+                "tst_mix_logprobs_f32: bad sizes");
+    TST_REQUIRE(n_models >= 1 && n_models <= MIX_MAX, TST_ERR_UNSUPPORTED, "tst_mix_logprobs_f32: 1 to %d models", MIX_MAX);
+    if (R == 0) return TST_OK;
+    hipLaunchKernelGGL(mix_logprobs_kernel, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, model_stride, ld,
+                       (int)n_models, weights, (int)V, out, ldo);
+    return tst_after_launch("tst_mix_logprobs_f32");
+}
 
 extern "C" int tst_gumbel_softmax_f32(const float* logits, int64_t ld, int64_t R, int64_t V, const float* u, int64_t ldu,
                                       float temperature, float* out, int64_t ldo, void* stream) {

@@ -54,6 +54,16 @@ def gumbel_softmax(logits, n_rows, n_cols, u, temperature, out):
          _p(out), out.stride(0), _stream())
 
 
+def mix_logprobs(stack, weights, n_rows, n_cols, out):
+    """out[:n_rows, :n_cols] = log(sum_i weights[i] * softmax(stack[i, :n_rows, :n_cols])); ``stack`` [n_models, rows, ld]"""
+    _chk(stack, torch.float32, 'stack'); _chk(weights, torch.float32, 'weights')
+    if not (out.is_cuda and out.dtype == torch.float32 and out.stride(-1) == 1):
+        raise ValueError('out must be an fp32 GPU tensor with unit inner stride')
+    assert stack.dim() == 3 and weights.numel() == stack.shape[0] and stack.shape[1] >= n_rows and stack.shape[2] >= n_cols
+    call('tst_mix_logprobs_f32', _p(stack), stack.stride(0), stack.stride(1), stack.shape[0], _p(weights), n_rows, n_cols,
+         _p(out), out.stride(0), _stream())
+
+
 def layernorm(x, gamma, beta, out, n_rows, eps=1e-5):
     """out = LayerNorm(x); ``out`` is fp32, or bf16 when it feeds a bf16 GEMM"""
     _chk(x, torch.float32, 'x'); _chk(gamma, torch.float32, 'gamma'); _chk(beta, torch.float32, 'beta')

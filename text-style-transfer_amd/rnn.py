@@ -138,6 +138,63 @@ class GRUSession:
         return self.logits
 
 
+class WeightedLMEnsemble:
+    """``WeightedLMEnsemble(models, weights)`` of ``/root/reference/src/prod/throwaway_models.py:9-36``: language models
+    that are stepped side by side; the prediction is log(sum_i w_i * softmax(logits_i)).  ``zs`` stacks the members'
+    states along a new first axis ([n_models, n_layers, B, H], batch axis 2, as at
+    ``/root/reference/src/prod/dialog_model.py:103,117``).  Members are models of this package with a ``session``."""
+
+    def __init__(self, models, weights):
+        assert len(models) == len(weights)
+        assert sum(weights) == 1
+        self.models, self.weights = list(models), list(weights)
+        self.device = self.models[0].device
+        self.V = self.models[0].V
+        if any(m.V != self.V for m in self.models):
+            raise ValueError('ensemble members must share one vocabulary')
+        self._w = torch.tensor(self.weights, dtype=torch.float32, device=self.device)
+
+    def session(self, zs, enc_mask=None, rows_per_sentence=1, max_len=None):
+        return EnsembleSession(self, zs, rows_per_sentence, max_len)
+
+    def __call__(self, zs, x, return_z=False):
+        """Teacher-forced evaluation: log-mixture [B, T, V] (and the stacked final states with ``return_z``)."""
+        results = [m(z, x, True) for m, z in zip(self.models, zs)]
+        B, T = x.shape
+        stack = torch.stack([r[0].reshape(B * T, self.V) for r in results]).contiguous()
+        out = torch.empty((B * T, self.V), dtype=torch.float32, device=self.device)
+        K.mix_logprobs(stack, self._w, B * T, self.V, out)
+        out = out.view(B, T, self.V)
+        return (out, torch.stack([r[1] for r in results])) if return_z else out
+
+
+class EnsembleSession:
+    needs_anc = False
+
+    def __init__(self, ens, zs, k, max_len):
+        self.ens, self.V = ens, ens.V
+        if zs.shape[0] != len(ens.models):
+            raise ValueError('zs must stack one state per member along its first axis')
+        self.members = [m.session(z, None, k, max_len) for m, z in zip(ens.models, zs)]
+        R = self.members[0].R
+        ldv = (self.V + 3) // 4 * 4
+        # the members write their logits into one stacked buffer, which the mixing kernel reads
+        self.stack = torch.empty((len(self.members), R, ldv), dtype=torch.float32, device=ens.device)
+        for i, s in enumerate(self.members):
+            s.logits = self.stack[i]
+        self.logits = torch.empty((R, ldv), dtype=torch.float32, device=ens.device)
+
+    def reorder(self, row_parent, n_rows, identity):
+        for s in self.members:
+            s.reorder(row_parent, n_rows, identity)
+
+    def step(self, rows, n, t):
+        for s in self.members:
+            s.step(rows, n, t)
+        K.mix_logprobs(self.stack, self.ens._w, n, self.V, self.logits)
+        return self.logits
+
+
 class RNNEncoder(HipModule):
     """``RNNEncoder(emb_size, hid_size, vocab, dropword_p, noise=...)``; ``encoder(x [B, T] ids) -> z [B, H]``, the
     final state of a one-layer GRU started at zero and run over all T positions (padding included, nothing is
