@@ -1,8 +1,9 @@
 """Builds ablated variants of the fp32 GEMM kernel (from the product source, by text substitution) next to
-this file as libgemm_<variant>.so; bench_variants.py times them.  Variants: BASE, NOBARRIER (no workgroup
-barrier; wrong results), NOSTAGE (no global loads / LDS stores of the next tiles), NOLDSREAD (operands not
-read from LDS), NOSTORE (epilogue stores disabled).  Measured on MI355X, vocabulary projection 32768 x 32000 x 256:
-BASE 120 TF, NOBARRIER 121, NOSTORE 120, NOSTAGE 135, NOLDSREAD 137 TFLOP/s."""
+this file as libgemm_<variant>.so; bench_variants.py times them (results of the ablated variants are wrong on
+purpose).  Variants: BASE; NOLDSREAD (operands not read from LDS); WIDEREAD (a quarter of the operand read
+instructions, each 16 bytes wide: the LDS instruction count of a k-permuted operand image at about the same bytes).
+Earlier measurements with this tool on the vocabulary projection 32768 x 32000 x 256: BASE 120 TF, no barrier 121,
+no epilogue stores 120, no staging 135, NOLDSREAD 137 TFLOP/s."""
 import os
 import subprocess
 
@@ -18,31 +19,33 @@ def sub(old, new):
 
 
 sub('#include "tst_common.h"', '#include "../../text-style-transfer_amd/csrc/tst_common.h"')
-sub("""                if (kt + 1 < nkt) {
-                    TST_STORE_TILE(nbuf);
-                    if (kt + 2 < nkt) TST_LOAD_TILE((kt + 2) * BK);
-                }
-                __syncthreads();""", """#ifndef ABL_NOSTAGE
-                if (kt + 1 < nkt) {
-                    TST_STORE_TILE(nbuf);
-                    if (kt + 2 < nkt) TST_LOAD_TILE((kt + 2) * BK);
-                }
-#endif
-#ifndef ABL_NOBARRIER
-                __syncthreads();
+sub("""#define TST_READ_OPERANDS(av, bv, bufi, kk)                                                                   \\
+    _Pragma("unroll") for (int i = 0; i < WTM; ++i) av[i] = As[bufi][(kk) + khalf][arow + 32 * i];            \\
+    _Pragma("unroll") for (int j = 0; j < WTN; ++j) bv[j] = Bs[bufi][(kk) + khalf][bcol + 32 * j];""",
+    """#if defined(ABL_NOLDSREAD)
+#define TST_READ_OPERANDS(av, bv, bufi, kk)                                                                   \\
+    _Pragma("unroll") for (int i = 0; i < WTM; ++i) av[i] = av[i] * 1.0001f;                                  \\
+    _Pragma("unroll") for (int j = 0; j < WTN; ++j) bv[j] = bv[j] * 1.0001f;
+#elif defined(ABL_WIDEREAD)
+#define TST_READ_OPERANDS(av, bv, bufi, kk)                                                                   \\
+    if (((kk) & 7) == 0) {                                                                                    \\
+        _Pragma("unroll") for (int i = 0; i < WTM; ++i) wa[i] = *reinterpret_cast<const float4*>(&As[bufi][(kk) + khalf][(arow & ~3) + 32 * i]); \\
+        _Pragma("unroll") for (int j = 0; j < WTN; ++j) wb[j] = *reinterpret_cast<const float4*>(&Bs[bufi][(kk) + khalf][(bcol & ~3) + 32 * j]); \\
+    }                                                                                                         \\
+    _Pragma("unroll") for (int i = 0; i < WTM; ++i) av[i] = ((kk) & 6) == 0 ? wa[i].x : ((kk) & 6) == 2 ? wa[i].y : ((kk) & 6) == 4 ? wa[i].z : wa[i].w; \\
+    _Pragma("unroll") for (int j = 0; j < WTN; ++j) bv[j] = ((kk) & 6) == 0 ? wb[j].x : ((kk) & 6) == 2 ? wb[j].y : ((kk) & 6) == 4 ? wb[j].z : wb[j].w;
+#else
+#define TST_READ_OPERANDS(av, bv, bufi, kk)                                                                   \\
+    _Pragma("unroll") for (int i = 0; i < WTM; ++i) av[i] = As[bufi][(kk) + khalf][arow + 32 * i];            \\
+    _Pragma("unroll") for (int j = 0; j < WTN; ++j) bv[j] = Bs[bufi][(kk) + khalf][bcol + 32 * j];
 #endif""")
-sub("av[i] = As[bufi][(kk) + khalf][arow + 32 * i];", "av[i] = ABL_RD(As[bufi][(kk) + khalf][arow + 32 * i], av[i]);")
-sub("bv[i] = Bs[bufi][(kk) + khalf][bcol + 32 * i];", "bv[i] = ABL_RD(Bs[bufi][(kk) + khalf][bcol + 32 * i], bv[i]);")
-sub("namespace {\n\nconstexpr int BK", "#ifdef ABL_NOLDSREAD\n#define ABL_RD(x, old) ((old) * 1.0001f)\n#else\n"
-    "#define ABL_RD(x, old) (x)\n#endif\nnamespace {\n\nconstexpr int BK")
-sub("float a_cur[WT], b_cur[WT], a_nxt[WT], b_nxt[WT];", "float a_cur[WT], b_cur[WT], a_nxt[WT], b_nxt[WT];\n"
-    "    for (int i = 0; i < WT; ++i) { a_nxt[i] = 1.f + lane; b_nxt[i] = 1.f; a_cur[i] = 2.f; b_cur[i] = 0.5f * lane; }")
-sub("cp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = v;",
-    "ABL_ST cp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = v;")
-sub("namespace {", "#ifdef ABL_NOSTORE\n#define ABL_ST if (v == 1234.5678f)\n#else\n#define ABL_ST\n#endif\nnamespace {")
+sub("    float a_cur[WTM], b_cur[WTN], a_nxt[WTM], b_nxt[WTN];",
+    "    float a_cur[WTM], b_cur[WTN], a_nxt[WTM], b_nxt[WTN];\n    float4 wa[WTM], wb[WTN];\n"
+    "    for (int i = 0; i < WTM; ++i) { a_nxt[i] = 1.f + lane; a_cur[i] = 2.f; wa[i] = make_float4(1.f, 2.f, 3.f, 4.f); }\n"
+    "    for (int j = 0; j < WTN; ++j) { b_nxt[j] = 1.f; b_cur[j] = 0.5f * lane; wb[j] = make_float4(1.f, 2.f, 3.f, 4.f); }")
 src = os.path.join(here, '_gemm_ablate.hip')
 open(src, 'w').write(s)
-for v in ('BASE', 'NOBARRIER', 'NOSTAGE', 'NOLDSREAD', 'NOSTORE'):
+for v in ('BASE', 'NOLDSREAD', 'WIDEREAD'):
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-fPIC', '-ffp-contract=off', '-std=c++17',
                            '-DABL_' + v, '-shared', '-o', os.path.join(here, 'libgemm_%s.so' % v), src,
                            os.path.join(csrc, 'capi.hip')])
