@@ -198,6 +198,46 @@ def tlm_case(InferenceState, name, hp, V, B, max_len, eos_bias, out_scale, seed,
     save(name, config, {'z': z.numpy()}, seqs, rec, finished_lens_of(seqs, max_len))
 
 
+def prefix_cases(InferenceState):
+    """The real loop started from a caller-provided ``active_seqs`` of token ids (``/root/reference/src/inference.py:37``):
+    a transformer decoder (whole-prefix mode) and a stateful GRU language model (which gets the whole prefix at its
+    first step, ``:128``)."""
+    rs = np.random.RandomState(110)
+    vocab = R.synthetic_vocab(64)
+    hp = R.mt_hp()
+    model = R.synthetic_init(R.Transformer(hp, vocab, vocab), vocab.stoi['<eos>'], 1.5, 2.0, seed=42)
+    B, S, max_len, t0 = 5, 9, 10, 3
+    lens = rs.randint(3, S + 1, size=B)
+    encs = torch.from_numpy(rs.standard_normal((B, S, hp.d_model)).astype(np.float32))
+    enc_mask = torch.from_numpy(np.arange(S)[None, :] < lens[:, None]).unsqueeze(1)
+    prefix = np.concatenate([np.full((B, 1), vocab.stoi['<bos>']), rs.randint(4, 64, size=(B, t0 - 1))], 1).astype(np.int64)
+    rec = Recorder(model.decoder, 4)
+    with torch.no_grad():
+        seqs = InferenceState({'model': rec, 'inputs': encs, 'enc_mask': enc_mask, 'vocab': vocab, 'max_len': max_len,
+                               'active_seqs': torch.from_numpy(prefix)}).inference()
+    seqs = [s.tolist() for s in seqs]
+    config = dict(kind='transformer', V=64, hp=dict(hp), weight_seed=42, eos_bias=1.5, out_scale=2.0, max_len=max_len,
+                  prefix_len=t0, source='reference src/inference.py with active_seqs')
+    save('prefix_tfm', config, {'encs': encs.numpy(), 'enc_mask': enc_mask.numpy(), 'prefix': prefix.astype(np.int32)}, seqs, rec,
+         [min(len(s) - (t0 - 1), max_len) for s in seqs])
+
+    vocab = R.synthetic_vocab(50, extra=('|',))
+    lm = R.synthetic_init(R.RNNLM(64, vocab, 2), vocab.stoi['|'], 1.0, 2.0, seed=42)
+    B, max_len, t0 = 4, 9, 4
+    z = torch.from_numpy(rs.standard_normal((2, B, 64)).astype(np.float32))
+    prefix = np.concatenate([np.full((B, 1), vocab.stoi['|']), rs.randint(5, 50, size=(B, t0 - 1))], 1).astype(np.int64)
+    rec = Recorder(lm, 4)
+    with torch.no_grad():
+        seqs = InferenceState({'model': rec, 'inputs': z, 'vocab': vocab, 'max_len': max_len, 'bos_token': '|', 'eos_token': '|',
+                               'substitute_inputs': True, 'inputs_batch_dim': 1, 'kwargs': {'return_z': True},
+                               'active_seqs': torch.from_numpy(prefix)}).inference()
+    seqs = [s.tolist() for s in seqs]
+    config = dict(kind='rnnlm_stateful', V=50, H=64, n_layers=2, weight_seed=42, eos_bias=1.0, out_scale=2.0, max_len=max_len,
+                  prefix_len=t0, source='reference src/inference.py (stateful) with active_seqs')
+    save('prefix_rnnlm', config, {'z': z.numpy(), 'prefix': prefix.astype(np.int32)}, seqs, rec,
+         [min(len(s) - (t0 - 1), max_len) for s in seqs])
+
+
 def ensemble_members(V, H, n_layers, seeds, eos_bias, out_scale):
     vocab = R.synthetic_vocab(V, extra=('|',))
     return vocab, [R.synthetic_init(R.RNNLM(H, vocab, n_layers), vocab.stoi['|'], eos_bias, out_scale, seed=sd) for sd in seeds]
@@ -374,6 +414,7 @@ def main():
     stateful_case(InferenceState, 'rnnlm_stateful', H=64, V=50, n_layers=2, B=4, max_len=14, eos_bias=1.0,
                   out_scale=2.0, seed=105)
     gumbel_op_case()
+    prefix_cases(InferenceState)
     ensemble_case(InferenceState, 'ensemble_rnnlm', V=50, H=32, n_layers=2, B=5, max_len=12, weights=[0.25, 0.75],
                   seeds=[42, 43], eos_bias=1.0, out_scale=2.0, seed=109)
     gumbel_case(InferenceState, 'gumbel_gru', 'gru', V=40, B=5, max_len=10, temperature=0.7, eos_bias=1.0, out_scale=2.0,

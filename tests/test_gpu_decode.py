@@ -316,3 +316,48 @@ def test_weighted_lm_ensemble_matches_reference_fixture(T):
     assert ok, err
     with pytest.raises(AssertionError):
         T.WeightedLMEnsemble(members, [0.5, 0.6])
+
+
+@pytest.mark.parametrize('name', ['prefix_tfm', 'prefix_rnnlm'])
+@pytest.mark.parametrize('how', ['native', 'foreign'])
+def test_id_prefix_matches_reference_fixture(T, name, how):
+    """``active_seqs`` given as token ids [B, t0] (/root/reference/src/inference.py:37): the sequences start with the
+    prefix and grow by up to max_len tokens; tokens identical to the real loop, logits within the fp32 tolerance.
+    'foreign': the torch specification model as an arbitrary callable (it gets the whole prefix like in the reference)."""
+    fx = load_fixture(name)
+    cfg = fx['config']
+    tmodel, model, vocab = native_models(T, cfg)
+    if how == 'foreign':
+        tmodel = tmodel.cuda()
+        model = tmodel
+        dec = tmodel.decoder if cfg['kind'] == 'transformer' else tmodel
+    else:
+        dec = model.decoder if cfg['kind'] == 'transformer' else model
+    prefix = torch.from_numpy(fx['prefix']).long().cuda()
+    if cfg['kind'] == 'transformer':
+        d = {'model': dec, 'inputs': torch.from_numpy(fx['encs']).cuda(), 'enc_mask': torch.from_numpy(fx['enc_mask']).cuda()}
+    else:
+        d = {'model': dec, 'inputs': torch.from_numpy(fx['z']).cuda(), 'bos_token': '|', 'eos_token': '|',
+             'substitute_inputs': True, 'inputs_batch_dim': 1, 'kwargs': {'return_z': True}}
+    d.update(vocab=vocab, max_len=cfg['max_len'], active_seqs=prefix)
+    st = T.InferenceState(d)
+    if how == 'native' and cfg['kind'] != 'transformer':
+        # the reference's stateful mode re-feeds prefix tokens at every step (its slice starts at the step number): the
+        # carried-state sessions of this package do not imitate that and refuse the combination
+        with pytest.raises(NotImplementedError):
+            st.inference()
+        return
+    out = st.inference(keep_logits=4)
+    assert seqs_of(out) == fx['seqs']
+    for i in range(sum(1 for k in fx if k.startswith('logits_s'))):
+        lg, sent, _ = st.loop.kept[i]
+        assert np.array_equal(sent.cpu().numpy(), fx['rows_s%d' % i])
+        ok, err = logits_close(lg.cpu().numpy(), fx['logits_s%d' % i])
+        assert ok, (i, err)
+    if how == 'native' and cfg['kind'] == 'transformer':   # beam of one == greedy with a prefix too; beam 3 runs
+        d1 = dict(d, beam_size=1)
+        assert seqs_of(T.InferenceState(d1).inference()) == fx['seqs']
+        b3 = T.InferenceState(dict(d, beam_size=3)).inference()
+        assert all(o[:3].tolist() == fx['prefix'][i].tolist() for i, o in enumerate(b3))
+    with pytest.raises(ValueError):
+        T.InferenceState(dict(d, active_seqs=prefix.float())).inference()

@@ -194,3 +194,23 @@ def test_ensemble_restatement_matches_reference_fixture():
     for i in range(sum(1 for k in fx if k.startswith('logits_s'))):
         assert np.array_equal(st.step_rows[i].numpy(), fx['rows_s%d' % i])
         assert np.array_equal(st.step_logits[i].numpy(), fx['logits_s%d' % i])
+
+
+@pytest.mark.parametrize('name', ['prefix_tfm', 'prefix_rnnlm'])
+def test_prefix_restatement_matches_reference_fixture(name):
+    """A caller-provided ``active_seqs`` of token ids (/root/reference/src/inference.py:37) under the restated loop."""
+    fx = load_fixture(name)
+    cfg = fx['config']
+    model, vocab = torch_model_for(cfg)
+    prefix = torch.from_numpy(fx['prefix']).long()
+    if cfg['kind'] == 'transformer':
+        state = {'model': model.decoder, 'inputs': torch.from_numpy(fx['encs']), 'enc_mask': torch.from_numpy(fx['enc_mask'])}
+    else:
+        state = {'model': model, 'inputs': torch.from_numpy(fx['z']), 'bos_token': '|', 'eos_token': '|',
+                 'substitute_inputs': True, 'inputs_batch_dim': 1, 'kwargs': {'return_z': True}}
+    state.update(vocab=vocab, max_len=cfg['max_len'], active_seqs=prefix)
+    st = R.RefInferenceState(state)
+    assert [s.tolist() for s in st.inference(keep_logits=4)] == fx['seqs']
+    for i in range(sum(1 for k in fx if k.startswith('logits_s'))):
+        assert np.array_equal(st.step_rows[i].numpy(), fx['rows_s%d' % i])
+        assert np.array_equal(st.step_logits[i].numpy(), fx['logits_s%d' % i])

@@ -12,6 +12,8 @@ A *session* provides:
   ``step(rows, n_rows, t) -> logits``   fp32 GPU tensor [>= n_rows, >= V], unit inner stride
   ``reorder(row_parent, n_rows, identity)``  called after each step with the old row of every new row
   ``takes_soft``      (optional) ``step`` accepts ``soft=`` token distributions [rows, Vp] in place of ``rows.tok``
+  ``incremental``     (optional) the session consumes one token per step (KV cache / carried state): a caller-provided
+                      prefix is then fed token by token before the loop; otherwise ``step`` reads the prefix from ``rows.hist``
 Rows: step 0 has one row per sentence (row a = sentence a, per-sentence state in rows 0..B-1 of buffers sized
 for B * beam rows); the first ``reorder`` fans every sentence out to ``beam`` consecutive rows.
 """
@@ -26,7 +28,8 @@ def length_penalty_table(max_len, alpha):
 
 
 class DecodeLoop:
-    def __init__(self, session, n_sent, beam, max_len, bos, eos, pad, alpha=0.0, device=None, sample=None, gumbel=None):
+    def __init__(self, session, n_sent, beam, max_len, bos, eos, pad, alpha=0.0, device=None, sample=None, gumbel=None,
+                 prefix=None):
         if not (1 <= beam <= 8):
             raise ValueError('beam_size must be in 1..8')
         if beam > session.V:
@@ -41,17 +44,31 @@ class DecodeLoop:
         dev = device or torch.device('cuda', torch.cuda.current_device())
         self.dev = dev
         R = n_sent * beam
-        self.cur = K.RowState(R, max_len, dev, session.needs_anc, pad)
-        self.nxt = K.RowState(R, max_len, dev, session.needs_anc, pad)
+        # A caller-provided prefix [B, t0] of token ids (``active_seqs`` of /root/reference/src/inference.py:37) takes the
+        # place of the single BOS: the loop then starts at position pos0 = t0 - 1 and every sequence may grow to
+        # t0 + max_len tokens; the prefix counts as pos0 tokens already emitted.
+        self.prefix = None if prefix is None else prefix.to(device=dev, dtype=torch.int32).contiguous()
+        self.pos0 = 0 if prefix is None else self.prefix.shape[1] - 1
+        self.Ttot = self.pos0 + max_len
+        if gumbel is not None and prefix is not None:
+            raise ValueError('an id prefix and gumbel decoding cannot be combined')
+        self.cur = K.RowState(R, self.Ttot, dev, session.needs_anc, pad)
+        self.nxt = K.RowState(R, self.Ttot, dev, session.needs_anc, pad)
         self.sel = K.Selection(R, dev)
         # Step 0 runs ONE row per sentence (all beams of a sentence would be identical): row a = sentence a.
         # The first merge fans each sentence out to its `beam` row slots.
         self.cur.hist[:, 0] = self.bos
         self.cur.tok.fill_(self.bos)
         self.cur.sent[:n_sent] = torch.arange(n_sent, dtype=torch.int32, device=dev)
-        self.lp = length_penalty_table(max_len, alpha).to(dev)
+        if self.prefix is not None:
+            self.cur.hist[:n_sent, :self.pos0 + 1] = self.prefix
+            self.cur.tok[:n_sent] = self.prefix[:, -1]
+            self.cur.nemit[:n_sent] = self.pos0
+            if self.cur.anc is not None and self.pos0 > 0:   # prefix positions live in the sentence's own row
+                self.cur.anc[:n_sent, :self.pos0] = self.cur.sent[:n_sent].unsqueeze(1)
+        self.lp = length_penalty_table(self.Ttot, alpha).to(dev)
         i32 = dict(dtype=torch.int32, device=dev)
-        self.out_tok = torch.full((n_sent, max_len + 1), pad, **i32)
+        self.out_tok = torch.full((n_sent, self.Ttot + 1), pad, **i32)
         self.out_len = torch.zeros(n_sent, **i32)
         self.out_score = torch.zeros(n_sent, dtype=torch.float32, device=dev)
         self.scratch = torch.zeros(2 * n_sent, **i32)
@@ -85,17 +102,23 @@ class DecodeLoop:
         self.select_log = None   # set to a list to collect (start, end, bytes) of every log-softmax/top-k launch
 
     def run(self, keep_logits=0):
-        """Runs the loop.  Returns (out_tok [B, T+1], out_len [B], out_score [B]) on the device; with
+        """Runs the loop.  Returns (out_tok [B, pos0 + T + 1], out_len [B], out_score [B]) on the device; with
         ``keep_logits`` > 0 also records (logits, sentence ids of the rows) of the first steps in
         ``self.kept`` (a debugging aid for the fp32 tolerance checks)."""
         s, k, T = self.s, self.k, self.T
         n_sent = self.B
+        pos0, Ttot = self.pos0, self.Ttot
         self.kept = []
+        if pos0 > 0 and getattr(s, 'incremental', False):   # feed the prefix, all but its last token, one token per step
+            for p in range(pos0):
+                self.cur.tok[:n_sent] = self.prefix[:, p]
+                s.step(self.cur, n_sent, p)
+            self.cur.tok[:n_sent] = self.prefix[:, -1]
         for t in range(T):
             k_in = 1 if t == 0 else k      # rows per sentence going into this step
             R = n_sent * k_in
             if self.gumbel is None:
-                logits = s.step(self.cur, R, t)
+                logits = s.step(self.cur, R, pos0 + t)
             else:
                 logits = s.step(self.cur, R, t, soft=self.dist_in)
             if t < keep_logits:
@@ -120,7 +143,7 @@ class DecodeLoop:
                     e1.record()
                     self.select_log.append((e0, e1, float(R) * s.V * logits.element_size()))
                 K.beam_merge(self.cur, self.top_val, self.top_idx, self.lse, n_sent, k, k_in, self.eos, self.sel)
-            K.retire_compact(self.cur, self.nxt, self.sel, self.lp, n_sent, k, t, T, self.eos, t == T - 1, self.top_ends,
+            K.retire_compact(self.cur, self.nxt, self.sel, self.lp, n_sent, k, pos0 + t, Ttot, self.eos, t == T - 1, self.top_ends,
                              self.out_tok, self.out_len, self.out_score, self.scratch, self.row_parent, self.n_alive)
             self.cur, self.nxt = self.nxt, self.cur
             self.steps_done += 1

@@ -15,6 +15,9 @@ so ``torch.manual_seed`` governs it like it governs the reference's ``Categorica
 CPU generator exactly as ``/root/reference/src/utils/gumbel.py:12`` does and copies them to the GPU, so the same
 ``torch.manual_seed`` gives the reference's noise; ``'device'`` draws them on the GPU).
 
+``active_seqs`` (``:37``): a caller-provided prefix of token ids ``[B, t0]`` replaces the single BOS; results start with
+it and may grow to ``t0 + max_len`` tokens (the loop still runs ``max_len`` steps, ``:155``).
+
 ``gumbel=True`` (``:83-88,104-105,136-138``): every step appends the distribution
 softmax((softmax(logits) + G) / temperature) instead of a token id, and the model is fed distributions.  In the
 reference this only runs when the caller passes ``active_seqs`` as distributions ``[B, 1, V]`` (ids cannot be
@@ -44,6 +47,7 @@ class ForeignSession:
         self.inputs, self.enc_mask = inputs, enc_mask   # one row per sentence until the first reorder fans out
         self.V = vocab_size
         self.soft_hist = None   # gumbel mode: the distributions fed so far, [rows, t, V]
+        self.pos0 = 0           # length of a caller-provided id prefix minus one (set by InferenceState)
 
     def step(self, rows, n, t, soft=None):
         if soft is None:
@@ -56,8 +60,8 @@ class ForeignSession:
                 raise NotImplementedError('gumbel decoding of a stateful model')
         args = [] if self.enc_mask is None else self.enc_mask
         with torch.no_grad():
-            if self.sub:
-                out, self.inputs = self.model(self.inputs, active[:, t:], *args, **self.kwargs)
+            if self.sub:   # /root/reference/src/inference.py:128: active_seqs[:, num_steps_done:], whatever the prefix length
+                out, self.inputs = self.model(self.inputs, active[:, t - self.pos0:], *args, **self.kwargs)
             else:
                 out = self.model(self.inputs, active, *args, **self.kwargs)
         logits = out[:, -1]
@@ -123,9 +127,9 @@ class InferenceState:
         assert self.bos_idx != self.vocab.stoi[self.unk_token]
         assert self.eos_idx != self.vocab.stoi[self.unk_token]
 
-    def _session(self):
+    def _session(self, n_positions=None):
         if hasattr(self.model, 'session') and not self.kwargs.get('force_foreign', False):
-            return self.model.session(self.inputs, self.enc_mask, self.beam_size, self.max_len)
+            return self.model.session(self.inputs, self.enc_mask, self.beam_size, n_positions or self.max_len)
         kwargs = {k: v for k, v in self.kwargs.items() if k != 'force_foreign'}
         return ForeignSession(self.model, self.inputs, self.enc_mask, kwargs, self.substitute_inputs,
                               self.inputs_batch_dim, self.beam_size, len(self.vocab))
@@ -139,8 +143,11 @@ class InferenceState:
                 raise ValueError("sample_type='sample' needs beam_size 1")
             seed = self.seed if self.seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
             sample = (float(self.temperature), seed)
+        prefix = None
         if self.active_seqs is not None and not self.gumbel:
-            raise NotImplementedError('a caller-provided active_seqs prefix is only supported with gumbel=True')
+            prefix = self.active_seqs
+            if prefix.dim() != 2 or prefix.shape[0] != self.batch_size or prefix.shape[1] < 1 or prefix.is_floating_point():
+                raise ValueError('active_seqs must be token ids [batch, t0 >= 1]')
         if not torch.cuda.is_available():
             raise RuntimeError('InferenceState needs a GPU: the decode loop runs in HIP kernels and has no CPU path')
         device = self.inputs.device if self.inputs.is_cuda else torch.device('cuda', torch.cuda.current_device())
@@ -155,20 +162,31 @@ class InferenceState:
                 raise ValueError("noise must be 'torch' or 'device'")
             V = len(self.vocab)
             if self.active_seqs is None:
-                prefix = torch.zeros((self.batch_size, V), dtype=torch.float32, device=device)
-                prefix[:, self.bos_idx] = 1.0
+                dist_prefix = torch.zeros((self.batch_size, V), dtype=torch.float32, device=device)
+                dist_prefix[:, self.bos_idx] = 1.0
             else:
                 if tuple(self.active_seqs.shape) != (self.batch_size, 1, V) or not self.active_seqs.is_floating_point():
                     raise NotImplementedError('gumbel=True takes active_seqs as one distribution per sentence: [B, 1, V] floats')
-                prefix = self.active_seqs[:, 0].to(device=device, dtype=torch.float32)
+                dist_prefix = self.active_seqs[:, 0].to(device=device, dtype=torch.float32)
             if self.noise == 'torch':
                 draw = lambda n, v: torch.rand((n, v)).to(device)            # noqa: E731
             else:
                 draw = lambda n, v: torch.rand((n, v), device=device)        # noqa: E731
-            gumbel = (float(self.temperature), prefix, draw)
+            gumbel = (float(self.temperature), dist_prefix, draw)
         with torch.cuda.device(device):
-            loop = DecodeLoop(self._session(), self.batch_size, self.beam_size, self.max_len, self.bos_idx,
-                              self.eos_idx, self.pad_idx, self.length_penalty, device, sample, gumbel)
+            total = self.max_len if prefix is None else self.max_len + prefix.shape[1] - 1
+            session = self._session(total)
+            if prefix is not None and prefix.shape[1] > 1:
+                if isinstance(session, ForeignSession):
+                    session.pos0 = prefix.shape[1] - 1
+                elif self.substitute_inputs:
+                    # /root/reference/src/inference.py:128 feeds active_seqs[:, num_steps_done:], so with a prefix of t0 > 1
+                    # tokens a stateful model is given t0 tokens at EVERY step (the last t0 - 1 of them again); a session
+                    # that carries its state consumes each token once and would give different results
+                    raise NotImplementedError('an id prefix longer than one token together with substitute_inputs is only '
+                                              'supported for foreign model callables')
+            loop = DecodeLoop(session, self.batch_size, self.beam_size, self.max_len, self.bos_idx,
+                              self.eos_idx, self.pad_idx, self.length_penalty, device, sample, gumbel, prefix)
             loop.select_log = getattr(self, 'select_log', None)
             loop.run(keep_logits)
         self.loop = loop

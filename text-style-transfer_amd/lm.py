@@ -142,6 +142,7 @@ class TransformerLMSession:
     [layer][position][row slot][3d] (addressed through the ancestor table, so beam reorders move nothing)
     and work buffers."""
     needs_anc = True
+    incremental = True
 
     def __init__(self, lm, z, k, max_len):
         self.lm, self.V = lm, lm.V

@@ -93,6 +93,7 @@ class GRUSession:
     is compacted or beams are reordered) and work buffers."""
     needs_anc = False
     takes_soft = True
+    incremental = True
 
     def __init__(self, model, z, k):
         self.m, self.V = model, model.V
@@ -170,6 +171,7 @@ class WeightedLMEnsemble:
 
 class EnsembleSession:
     needs_anc = False
+    incremental = True
 
     def __init__(self, ens, zs, k, max_len):
         self.ens, self.V = ens, ens.V

@@ -219,6 +219,7 @@ class TransformerSession:
     (computed once), the self-attention q|k|v cache [layer][position][row slot][3d] and work buffers."""
     needs_anc = True
     takes_soft = True
+    incremental = True
 
     def __init__(self, dec, encs, enc_mask, k, max_len):
         self.dec, self.V = dec, dec.V
