@@ -238,6 +238,33 @@ def prefix_cases(InferenceState):
          [min(len(s) - (t0 - 1), max_len) for s in seqs])
 
 
+def charlm_case(InferenceState):
+    """The REAL ``CharLMFromEmbs`` (/root/reference/src/prod/throwaway_models.py:38-55) around a specification RNNLM:
+    ``init_z`` from a style embedding, then the stateful loop of /root/reference/src/prod/dialog_model.py:97-120 (greedy)."""
+    from src.prod.throwaway_models import CharLMFromEmbs
+    import torch.nn as nn
+    vocab = R.synthetic_vocab(50, extra=('|',))
+    lm = R.synthetic_init(R.RNNLM(64, vocab, 2), vocab.stoi['|'], 0.2, 2.0, seed=42)
+    rs = np.random.RandomState(111)
+    emb = nn.Embedding(2, 64)
+    with torch.no_grad():
+        emb.weight.copy_(torch.from_numpy(rs.standard_normal((2, 64)).astype(np.float32)))
+    model = CharLMFromEmbs(lm, emb, 2).eval()
+    B, max_len = 4, 10
+    text = torch.from_numpy(rs.randint(5, 50, size=(B, 6)))
+    with torch.no_grad():
+        z0 = model.init_z(B, 1)
+        z = model(z0, text, return_z=True)[1]
+        rec = Recorder(model, 4)
+        seqs = InferenceState({'model': rec, 'inputs': z, 'vocab': vocab, 'max_len': max_len, 'bos_token': '|', 'eos_token': '|',
+                               'substitute_inputs': True, 'inputs_batch_dim': 1, 'kwargs': {'return_z': True}}).inference()
+    seqs = [s.tolist() for s in seqs]
+    config = dict(kind='rnnlm_stateful', V=50, H=64, n_layers=2, weight_seed=42, eos_bias=0.2, out_scale=2.0, max_len=max_len,
+                  source='reference CharLMFromEmbs + src/inference.py (stateful)')
+    save('charlm_embs', config, {'style_embed': emb.weight.detach().numpy(), 'text': text.numpy().astype(np.int32),
+                                 'z0': z0.numpy(), 'z': z.numpy()}, seqs, rec, finished_lens_of(seqs, max_len))
+
+
 def ensemble_members(V, H, n_layers, seeds, eos_bias, out_scale):
     vocab = R.synthetic_vocab(V, extra=('|',))
     return vocab, [R.synthetic_init(R.RNNLM(H, vocab, n_layers), vocab.stoi['|'], eos_bias, out_scale, seed=sd) for sd in seeds]
@@ -415,6 +442,7 @@ def main():
                   out_scale=2.0, seed=105)
     gumbel_op_case()
     prefix_cases(InferenceState)
+    charlm_case(InferenceState)
     ensemble_case(InferenceState, 'ensemble_rnnlm', V=50, H=32, n_layers=2, B=5, max_len=12, weights=[0.25, 0.75],
                   seeds=[42, 43], eos_bias=1.0, out_scale=2.0, seed=109)
     gumbel_case(InferenceState, 'gumbel_gru', 'gru', V=40, B=5, max_len=10, temperature=0.7, eos_bias=1.0, out_scale=2.0,

@@ -361,3 +361,22 @@ def test_id_prefix_matches_reference_fixture(T, name, how):
         assert all(o[:3].tolist() == fx['prefix'][i].tolist() for i, o in enumerate(b3))
     with pytest.raises(ValueError):
         T.InferenceState(dict(d, active_seqs=prefix.float())).inference()
+
+
+def test_char_lm_from_embs_matches_reference_fixture(T):
+    """CharLMFromEmbs (/root/reference/src/prod/throwaway_models.py:38-55): init_z from the style embedding, the context
+    pass lm(z0, text, return_z=True) and the stateful decode of /root/reference/src/prod/dialog_model.py:97-120 against
+    the real class under the real loop."""
+    fx = load_fixture('charlm_embs')
+    cfg = fx['config']
+    tmodel, lm, vocab = native_models(T, cfg)
+    model = T.CharLMFromEmbs(lm, torch.from_numpy(fx['style_embed']), cfg['n_layers'])
+    z0 = model.init_z(fx['text'].shape[0], 1)
+    assert np.array_equal(z0.cpu().numpy(), fx['z0'])
+    z = model(z0, torch.from_numpy(fx['text']).long().cuda(), return_z=True)[1]
+    ok, err = logits_close(z.cpu().numpy(), fx['z'])
+    assert ok, err
+    st = T.InferenceState({'model': model, 'inputs': torch.from_numpy(fx['z']).cuda(), 'vocab': vocab, 'max_len': cfg['max_len'],
+                           'bos_token': '|', 'eos_token': '|', 'substitute_inputs': True, 'inputs_batch_dim': 1,
+                           'kwargs': {'return_z': True}})
+    assert seqs_of(st.inference()) == fx['seqs']

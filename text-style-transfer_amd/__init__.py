@@ -10,10 +10,10 @@ from .vocab import Vocab
 from .inference import InferenceState, simple_inference
 from .transformer import HP, Transformer, TransformerDecoder
 from .encoder import TransformerEncoder
-from .rnn import Generator, RNNDecoder, RNNEncoder, RNNLM, WeightedLMEnsemble
+from .rnn import CharLMFromEmbs, Generator, RNNDecoder, RNNEncoder, RNNLM, WeightedLMEnsemble
 from .lm import TransformerLM
 from .postprocess import itos_many, compute_bleu_for_sents, corpus_bleu
 
 __all__ = ['InferenceState', 'simple_inference', 'Vocab', 'HP', 'Transformer', 'TransformerDecoder',
-           'TransformerEncoder', 'RNNDecoder', 'RNNEncoder', 'Generator', 'RNNLM', 'WeightedLMEnsemble', 'TransformerLM', 'itos_many', 'compute_bleu_for_sents', 'corpus_bleu', 'TstError',
+           'TransformerEncoder', 'RNNDecoder', 'RNNEncoder', 'Generator', 'RNNLM', 'WeightedLMEnsemble', 'CharLMFromEmbs', 'TransformerLM', 'itos_many', 'compute_bleu_for_sents', 'corpus_bleu', 'TstError',
            'version']

@@ -139,6 +139,28 @@ class GRUSession:
         return self.logits
 
 
+class CharLMFromEmbs:
+    """``CharLMFromEmbs(rnn_lm, style_embed, n_layers)`` of ``/root/reference/src/prod/throwaway_models.py:38-55``: a GRU
+    language model whose initial state is a learned style embedding.  ``rnn_lm`` is an ``RNNLM`` of this package,
+    ``style_embed`` the embedding matrix [n_styles, H] (a tensor, or anything with a ``.weight``)."""
+
+    def __init__(self, rnn_lm, style_embed, n_layers):
+        self.n_layers, self.lm = n_layers, rnn_lm
+        w = style_embed.weight if hasattr(style_embed, 'weight') else style_embed
+        self.style_embed = w.detach().to(device=rnn_lm.device, dtype=torch.float32).contiguous()
+        self.device, self.V = rnn_lm.device, rnn_lm.V
+
+    def __call__(self, z, x, return_z=False):
+        return self.lm(z, x, return_z=return_z)
+
+    def init_z(self, batch_size, style):
+        """[n_layers, batch_size, H]: the embedding of ``style`` for every layer and sentence."""
+        return self.style_embed[int(style)].expand(self.n_layers, batch_size, -1).contiguous()
+
+    def session(self, z, enc_mask=None, rows_per_sentence=1, max_len=None):
+        return self.lm.session(z, enc_mask, rows_per_sentence, max_len)
+
+
 class WeightedLMEnsemble:
     """``WeightedLMEnsemble(models, weights)`` of ``/root/reference/src/prod/throwaway_models.py:9-36``: language models
     that are stepped side by side; the prediction is log(sum_i w_i * softmax(logits_i)).  ``zs`` stacks the members'
