@@ -380,3 +380,33 @@ def test_char_lm_from_embs_matches_reference_fixture(T):
                            'bos_token': '|', 'eos_token': '|', 'substitute_inputs': True, 'inputs_batch_dim': 1,
                            'kwargs': {'return_z': True}})
     assert seqs_of(st.inference()) == fx['seqs']
+
+
+def test_embed_and_gru_submodules_as_the_prod_callers_use_them(T):
+    """``decoder.embed(ids)`` and ``decoder.gru(embs, z.unsqueeze(0))[1].squeeze(0)`` (/root/reference/src/prod/style_model.py:64,68),
+    ``lm.gru(lm.embed(text))[1]`` (/root/reference/src/prod/dialog_model.py:105-106): against the nn.Embedding / nn.GRU of the
+    specification modules (fp32 tolerance) and the canonical oracle (bit for bit)."""
+    fx = load_fixture('rnnlm_stateful')
+    cfg = fx['config']
+    tmodel, lm, vocab = native_models(T, cfg)                      # 2-layer RNNLM
+    r = np.random.RandomState(8)
+    ids = torch.from_numpy(r.randint(0, cfg['V'], size=(9, 5)))
+    z = torch.from_numpy(r.standard_normal((cfg['n_layers'], 9, cfg['H'])).astype(np.float32))
+    embs = lm.embed(ids.cuda())
+    with torch.no_grad():
+        want_e = tmodel.embed(ids)
+        want_o, want_h = tmodel.gru(want_e, z)
+        want_o0, want_h0 = tmodel.gru(want_e)
+    assert np.array_equal(embs.cpu().numpy(), want_e.numpy())
+    out, h_n = lm.gru(embs, z.cuda())
+    for got, want in ((out, want_o), (h_n, want_h)):
+        ok, err = logits_close(got.cpu().numpy(), want.numpy())
+        assert ok, err
+    out0, h0 = lm.gru(embs)
+    ok, err = logits_close(h0.cpu().numpy(), want_h0.numpy())
+    assert ok, err
+    # canonical oracle: step the same cells token by token
+    sess = C.CanonGRUDecoder(tmodel).session(z.numpy())
+    for t in range(ids.shape[1]):
+        sess.step(ids[:, t].numpy().astype(np.int32), t)
+    assert np.array_equal(h_n.cpu().numpy(), np.stack(sess.h))

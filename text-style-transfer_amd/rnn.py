@@ -58,6 +58,41 @@ class _GRUModel(HipModule):
     def session(self, z, enc_mask=None, rows_per_sentence=1, max_len=None):
         return GRUSession(self, z, rows_per_sentence)
 
+    # The two sub-modules that callers of the reference use directly (``decoder.embed(ids)``, ``decoder.gru(embs, z)[1]``
+    # at /root/reference/src/prod/style_model.py:64,68; ``lm.embed(text)``, ``lm.gru(embs)[1]`` at
+    # /root/reference/src/prod/dialog_model.py:105-106), with the calling conventions of nn.Embedding and of a
+    # batch_first nn.GRU.
+    def embed(self, ids):
+        """ids [B, T] -> embeddings [B, T, E]"""
+        W = self.prepared()
+        B, T = ids.shape
+        out = torch.empty((B * T, self.E), dtype=torch.float32, device=self.device)
+        K.embed_posadd(ids.to(device=self.device, dtype=torch.int32).contiguous().view(-1), W['emb'], None, 1.0, out, B * T)
+        return out.view(B, T, self.E)
+
+    def gru(self, embs, h0=None):
+        """embs [B, T, E], h0 [n_layers, B, H] (zeros if omitted) -> (outputs of the last layer [B, T, H], final states
+        [n_layers, B, H]).  Layer by layer: the input products of all positions of a layer are one GEMM."""
+        W = self.prepared()
+        B, T, _ = embs.shape
+        f32 = dict(dtype=torch.float32, device=self.device)
+        x = embs.to(**f32).transpose(0, 1).contiguous().view(T * B, -1)       # position-major rows t * B + b
+        h_n = []
+        gh = torch.empty((B, 3 * self.H), **f32)
+        for l, c in enumerate(W['cells']):
+            gi = torch.empty((T * B, 3 * self.H), **f32)
+            K.gemm(x, c['wih'], c['bih'], gi, T * B)
+            h = torch.zeros((B, self.H), **f32) if h0 is None else h0[l].to(**f32).contiguous().clone()
+            out = torch.empty((T * B, self.H), **f32)
+            for t in range(T):
+                K.gemm(h, c['whh'], c['bhh'], gh, B)
+                h_new = out[t * B:(t + 1) * B]
+                K.gru_cell_step(gi[t * B:(t + 1) * B], gh, h, h_new, B)
+                h = h_new
+            h_n.append(h.clone())
+            x = out
+        return x.view(T, B, self.H).transpose(0, 1).contiguous(), torch.stack(h_n)
+
     def _run_prefix(self, z, x):
         """Teacher-forced evaluation: logits [B,T,V] and the final state [n_layers,B,H]."""
         B, T = x.shape
