@@ -231,3 +231,26 @@ def test_lm_bf16_beam_properties(T):
     perm = np.random.RandomState(0).permutation(32)
     assert run(perm[:11], 8) == [full8[i] for i in perm[:11]]
     assert all(s[0] == 2 and 3 not in s and len(s) <= 21 for s in full8)
+
+
+def test_dtype_and_return_logits_keys(T):
+    """Additive keys of the state dict: ``dtype`` switches a TransformerLM between fp32 and bf16 (and must name fp32
+    for models that only compute in fp32), ``return_logits`` keeps the last-position logits of every step."""
+    tmodel, lm, vocab, z = random_lm_case(T, 'fp32', B=6, eos_bias=0.0)
+    d = {'model': lm, 'inputs': torch.from_numpy(z).cuda(), 'vocab': vocab, 'max_len': 8}
+    st32 = T.InferenceState(dict(d, dtype='fp32', return_logits=True))
+    out32 = [s.tolist() for s in st32.inference()]
+    assert len(st32.step_logits) == st32.num_steps_done and st32.step_logits[0][0].dtype == torch.float32
+    assert tuple(st32.step_logits[0][0].shape) == (6, len(vocab)) and st32.step_logits[0][1].tolist() == list(range(6))
+    st16 = T.InferenceState(dict(d, dtype='bf16', return_logits=True))
+    st16.inference()
+    assert lm.dtype == 'bf16' and st16.step_logits[0][0].dtype == torch.bfloat16
+    a, b = st16.step_logits[0][0].float(), st32.step_logits[0][0]
+    assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max())
+    assert [s.tolist() for s in T.InferenceState(dict(d, dtype='fp32')).inference()] == out32 and lm.dtype == 'fp32'
+    with pytest.raises(ValueError):
+        T.InferenceState(dict(d, dtype='fp16')).inference()
+    vocab_g = T.Vocab.synthetic(40)
+    gru = T.RNNDecoder(32, 32, vocab_g)
+    with pytest.raises(ValueError):
+        T.InferenceState({'model': gru, 'inputs': torch.zeros(2, 32).cuda(), 'vocab': vocab_g, 'dtype': 'bf16'}).inference()

@@ -7,7 +7,7 @@ happens: token selection, EOS retirement, batch compaction and the hypothesis bo
 kernels on device-resident state (``engine.DecodeLoop``), and models of this package are stepped
 incrementally (KV cache / carried GRU state) instead of being re-run on the whole prefix (``:132``).
 
-Additive keys (not in the reference): ``beam_size`` (1 = the reference's greedy arg-max; the reference
+Additive keys (not in the reference): ``dtype`` / ``return_logits`` (see the constructor), ``beam_size`` (1 = the reference's greedy arg-max; the reference
 has no beam search), ``length_penalty`` (alpha of ((5 + n) / 6) ** alpha, used to rank finished beams),
 ``seed`` (makes ``sample_type='sample'`` reproducible; by default a seed is drawn from torch's generator,
 so ``torch.manual_seed`` governs it like it governs the reference's ``Categorical.sample``),
@@ -113,6 +113,12 @@ class InferenceState:
         self.length_penalty = state_dict.get('length_penalty', 0.0)
         self.seed = state_dict.get('seed')  # sampling only; default: drawn from torch's global generator
         self.noise = state_dict.get('noise', 'torch')  # gumbel only: where the uniform draws come from
+        # 'dtype': 'fp32' | 'bf16' selects the arithmetic of a model that can switch (TransformerLM); for any other model
+        # it must name what the model computes in (fp32).  'return_logits': keep the last-position logits of every step
+        # in ``self.step_logits`` as (logits [rows, V], sentence index of every row), a debugging aid.
+        self.dtype = state_dict.get('dtype')
+        self.return_logits = state_dict.get('return_logits', False)
+        self.step_logits = []
 
         self.finished = [None for _ in range(self.batch_size)]
         self.num_steps_done = 0
@@ -135,6 +141,16 @@ class InferenceState:
                               self.inputs_batch_dim, self.beam_size, len(self.vocab))
 
     def _run(self, keep_logits=0):
+        if self.return_logits:
+            keep_logits = self.max_len
+        if self.dtype is not None:
+            if self.dtype not in ('fp32', 'bf16'):
+                raise ValueError("dtype must be 'fp32' or 'bf16'")
+            have = getattr(self.model, 'dtype', 'fp32')
+            if have != self.dtype:
+                if not hasattr(self.model, 'set_dtype'):
+                    raise ValueError('the model computes in %s, dtype=%r was asked for' % (have, self.dtype))
+                self.model.set_dtype(self.dtype)
         if self.sample_type not in ('max', 'sample'):
             raise NotImplementedError  # as /root/reference/src/inference.py:149
         sample = None
@@ -190,6 +206,7 @@ class InferenceState:
             loop.select_log = getattr(self, 'select_log', None)
             loop.run(keep_logits)
         self.loop = loop
+        self.step_logits = [(lg, sent) for lg, sent, _ in loop.kept]
         self.num_steps_done = loop.steps_done
         self.scores = loop.out_score
         return loop

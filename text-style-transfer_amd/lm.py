@@ -83,6 +83,14 @@ class TransformerLM(HipModule):
         return self._prepared
 
     # ---- step-wise protocol used by the decode loop -------------------------------------------------
+    def set_dtype(self, dtype):
+        """Switches between fp32 and bf16 arithmetic (the parameters stay fp32; the kernel-side copies are rebuilt)."""
+        if dtype not in ('fp32', 'bf16'):
+            raise ValueError("dtype must be 'fp32' or 'bf16'")
+        if dtype != self.dtype:
+            self.dtype = dtype
+            self._prepared = None
+
     def session(self, z, enc_mask=None, rows_per_sentence=1, max_len=None):
         return TransformerLMSession(self, z, rows_per_sentence, max_len if max_len is not None else self.pe_max_len)
 
