@@ -79,6 +79,32 @@ def cpu_baseline(eos_bias, sample, min_seconds=10.0):
                       % (passes, sample, MAX_LEN, VOCAB, toks, dt)}
 
 
+def cpu_baseline_kv_cached(eos_bias, sample, min_seconds=5.0):
+    """The same sentences on the host cores with the ALGORITHMIC change of this build but none of its hardware: the
+    canonical-arithmetic C oracle (KV cache, one new token per step; OpenMP over rows).  Reported beside ``cpu_baseline``
+    so that the speed-up of the incremental algorithm and that of the GPU are not conflated."""
+    from oracle import canon as C
+    from oracle import torch_ref as R
+    from tst_amd import synthetic
+    vocab = R.synthetic_vocab(VOCAB)
+    model = R.synthetic_init(R.Transformer(R.HP(HP), vocab, vocab), vocab.stoi['<eos>'], eos_bias, OUT_SCALE, seed=42)
+    src = synthetic.multi30k_like_sources(256, VOCAB, seed=1235)[:sample]
+    dec = C.CanonTransformerDecoder(model.decoder, HP['n_heads'])
+    toks = passes = 0
+    t0 = time.time()
+    while passes < 8 and time.time() - t0 < min_seconds:
+        with torch.no_grad():
+            encs, enc_mask = model.encoder(src)
+        sess = dec.session(encs.numpy(), enc_mask.numpy(), 1, MAX_LEN)
+        seqs = C.greedy_decode(sess, src.shape[0], MAX_LEN, vocab.stoi['<bos>'], vocab.stoi['<eos>'])[0]
+        toks += sum(len(s) - 1 for s in seqs)
+        passes += 1
+    dt = time.time() - t0
+    return {'value': toks / dt, 'unit': 'tokens/s', 'cores': int(os.environ.get('OMP_NUM_THREADS', os.cpu_count() or 1)),
+            'kind': 'port', 'sample': '%d pass(es) over %d sentences of BASELINE config 1, %d tokens in %.1f s; C oracle with a KV '
+                                      'cache (fixed-order fp32), greedy' % (passes, src.shape[0], toks, dt)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -198,6 +224,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.eos_bias, args.cpu_sample)
+            result['cpu_baseline_kv_cached'] = cpu_baseline_kv_cached(args.eos_bias, args.cpu_sample)
         print(json.dumps(result))
     if world > 1:
         dist.destroy_process_group()
