@@ -276,7 +276,7 @@ class TransformerLM(nn.Module):
     def forward(self, z, x):
         t = x.shape[1]
         causal = torch.ones(t, t, dtype=torch.bool, device=x.device).tril().view(1, 1, t, t)
-        h = self.embed(x) * math.sqrt(self.d_model) + self.pe[:t] + z.unsqueeze(1)
+        h = embed_tokens(self.embed, x) * math.sqrt(self.d_model) + self.pe[:t] + z.unsqueeze(1)
         for layer in self.layers:
             h = layer(h, causal)
         return self.out(self.ln(h))

@@ -169,3 +169,48 @@ def test_gumbel_rejects_what_the_reference_cannot_do(T):
         T.InferenceState(state_dict_for(fx, model, vocab, substitute_inputs=True)).inference()
     with pytest.raises(NotImplementedError):
         T.InferenceState(state_dict_for(fx, model, vocab, active_seqs=torch.zeros(5, 2, 40))).inference()
+
+
+def test_gumbel_transformer_lm_against_restated_loop(T):
+    """The z-conditioned transformer LM in soft mode against the restated reference loop on the torch specification
+    (which the gumbel fixtures pin to the real loop), with the same uniform draws."""
+    hp = dict(model_size=64, n_layers=2, n_heads=4, d_ff=128, pe_max_len=32)
+    V, B, max_len = 90, 5, 7
+    tv = R.synthetic_vocab(V)
+    tmodel = R.synthetic_init(R.TransformerLM(R.HP(hp), tv), 3, 2.0, 2.0, seed=9)
+    vocab = T.Vocab.synthetic(V)
+    lm = T.TransformerLM(T.HP(hp), vocab)
+    lm.load_state_dict(tmodel.state_dict())
+    r = np.random.RandomState(12)
+    z = (0.3 * r.standard_normal((B, 64))).astype(np.float32)
+    draws = [r.random_sample((B, V)).astype(np.float32) for _ in range(max_len)]
+    prefix = torch.zeros(B, 1, V)
+    prefix[:, 0, 2] = 1.0
+    # reference side: rows leave the batch when they end, so the draws of step i are the first n_active rows
+    class Shrinking(replay_rand):
+        def __enter__(self):
+            outer = self
+            super().__enter__()
+            fake = torch.rand
+
+            def shaped(*size, **kw):
+                shape = tuple(size[0]) if len(size) == 1 and not isinstance(size[0], int) else tuple(size)
+                outer.draws[outer.i] = outer.draws[outer.i][:shape[0]]
+                return fake(*size, **kw)
+            torch.rand = shaped
+            return self
+    with Shrinking(list(draws)):
+        want = R.RefInferenceState({'model': R.SoftInput(tmodel, V), 'inputs': torch.from_numpy(z), 'vocab': tv, 'max_len': max_len,
+                                    'gumbel': True, 'temperature': 0.8, 'active_seqs': prefix}).inference()
+    with Shrinking(list(draws)):
+        got = T.InferenceState({'model': lm, 'inputs': torch.from_numpy(z).cuda(), 'vocab': vocab, 'max_len': max_len,
+                                'gumbel': True, 'temperature': 0.8, 'active_seqs': prefix}).inference()
+    assert [tuple(g.shape) for g in got] == [tuple(w.shape) for w in want]
+    for g, w in zip(got, want):
+        ok, err = close(g.cpu().numpy(), w.numpy())
+        assert ok, err
+    lm16 = T.TransformerLM(T.HP(hp), vocab, dtype='bf16')
+    lm16.load_state_dict(tmodel.state_dict())
+    with pytest.raises(ValueError):      # the soft step needs fp32 logits
+        T.InferenceState({'model': lm16, 'inputs': torch.from_numpy(z).cuda(), 'vocab': vocab, 'max_len': 3, 'gumbel': True,
+                          'noise': 'device'}).inference()

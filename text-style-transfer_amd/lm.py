@@ -18,7 +18,7 @@ from collections import OrderedDict
 import torch
 
 from . import kernels as K
-from .transformer import HP, HipModule, _t, sinusoid_table
+from .transformer import _pad_rows4, HP, HipModule, _t, sinusoid_table
 
 
 class TransformerLM(HipModule):
@@ -151,6 +151,7 @@ class TransformerLMSession:
     and work buffers."""
     needs_anc = True
     incremental = True
+    takes_soft = True
 
     def __init__(self, lm, z, k, max_len):
         self.lm, self.V = lm, lm.V
@@ -180,11 +181,17 @@ class TransformerLMSession:
     def reorder(self, row_parent, n_rows, identity):
         pass  # the KV cache is addressed through the ancestor table; nothing moves
 
-    def step(self, rows, n, t):
+    def step(self, rows, n, t, soft=None):
+        """Logits of the next token; ``soft`` (token distributions [>= n, Vp] fp32) replaces the lookup of ``rows.tok``."""
         lm, W, gemm = self.lm, self.lm.prepared(), self.gemm
         d, H = lm.d, lm.heads
         x, h, a, ff = self.x, self.h, self.a, self.ff
-        K.embed_posadd(rows.tok, W['emb'], W['pe'][t], self.scale, x, n)
+        if soft is None:
+            K.embed_posadd(rows.tok, W['emb'], W['pe'][t], self.scale, x, n)
+        else:
+            if 'emb_pad' not in W:
+                W['emb_pad'] = _pad_rows4(W['emb'])
+            K.soft_embed(soft, W['emb_pad'], self.scale, W['pe'][t], x, n)
         K.add_rows(x, self.z, rows.sent, n)
         for li, L in enumerate(W['layers']):
             K.layernorm(x, L['ln1'][0], L['ln1'][1], h, n)
