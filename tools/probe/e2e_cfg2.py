@@ -13,7 +13,7 @@ dev = torch.device('cuda', 0)
 model, vocab = bench.build_model(dev, 5.5)
 src = synthetic.multi30k_like_sources(8192, bench.VOCAB, seed=1236).to(dev)
 model.decoder.event_log = None
-for rep in range(4):
+for rep in range(int(os.environ.get("REPS", "4"))):
     torch.cuda.synchronize(); t0 = time.time()
     tok, lens, loop = bench.decode_batch(model, vocab, src, 4, 0.0)
     n = int((lens.cpu().long() - 1).clamp(min=0).sum())
