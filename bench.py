@@ -15,6 +15,7 @@ launches inside the timed steps.  ``cpu_baseline`` times the CPU restatement of 
 BASELINE.json config 1 on the host cores (rank 0, N = 1 only).
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -157,11 +158,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    select_timing = []
+    # HIP events around every vocabulary-projection and selection launch of the timed steps, made before the timed region
+    from tst_amd.timing import LaunchTimer
+    launches = args.steps * (MAX_LEN + 2)
+    timing, select_timing = LaunchTimer(launches), LaunchTimer(launches)
 
-    def step(timing):
-        model.decoder.event_log = timing   # HIP events around every vocabulary-projection launch
-        tok, lens, loop = decode_batch(model, vocab, src, args.beam, args.alpha, None if timing is None else select_timing)
+    def step(timed):
+        model.decoder.event_log = timing if timed else None
+        tok, lens, loop = decode_batch(model, vocab, src, args.beam, args.alpha, select_timing if timed else None)
         if world > 1:
             if args.backend != 'nccl':          # rehearsal backend: gathers host tensors
                 tok, lens = tok.cpu(), lens.cpu()
@@ -170,31 +174,32 @@ def main():
         return tok_h, lens_h, loop
 
     for _ in range(args.warmup):
-        step(None)
-    timing = []
+        step(False)
+    gc.collect()
+    gc.disable()      # no collector pauses of the launching thread inside the timed region
     barrier()
     t0 = time.time()
     emitted = 0
     rows_stepped = 0
     n_steps_loop = 0
     for _ in range(args.steps):
-        tok_h, lens_h, loop = step(timing)
+        tok_h, lens_h, loop = step(True)
         emitted += int((lens_h.long() - 1).clamp(min=0).sum())   # all ranks' sentences when gathered
         rows_stepped += loop.rows_stepped
         n_steps_loop += loop.steps_done
     barrier()
     dt = time.time() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
     if rank == 0:
-        gemm_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in timing)
-        gemm_flops = sum(f for _, _, f in timing)
+        gemm_ms, gemm_flops, gemm_launches = timing.totals()
         achieved = gemm_flops / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
-        sel_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in select_timing)
-        sel_gbs = sum(b for _, _, b in select_timing) / (sel_ms * 1e-3) / 1e9 if sel_ms > 0 else 0.0
+        sel_ms, sel_bytes, sel_launches = select_timing.totals()
+        sel_gbs = sel_bytes / (sel_ms * 1e-3) / 1e9 if sel_ms > 0 else 0.0
         traffic = None   # HBM bytes per vocabulary-projection launch from the committed PMC passes of this command
         if os.path.exists(TRAFFIC_FILE):
             with open(TRAFFIC_FILE) as f:
@@ -214,13 +219,13 @@ def main():
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                          'frac': achieved / FP32_MATRIX_PEAK_TFLOPS, 'traffic': traffic,
                          'kernel': 'gemm_f32_kernel (vocabulary projection [rows,256]x[256,32000], fp32 MFMA)',
-                         'launches': len(timing), 'avg_launch_ms': gemm_ms / max(1, len(timing)),
+                         'launches': gemm_launches, 'avg_launch_ms': gemm_ms / max(1, gemm_launches),
                          'share_of_step_time': gemm_ms * 1e-3 / dt},
             # second kernel by time, the HBM-bound pass over the [rows, V] logits (algorithmic bytes: every logit once)
             'roofline_select': {'bound': 'hbm', 'achieved': sel_gbs, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                                 'frac': sel_gbs / HBM_PEAK_GBS, 'kernel': 'logsoftmax_topk_kernel (log-sum-exp + top-%d over V=%d)'
-                                % (args.beam, VOCAB), 'launches': len(select_timing),
-                                'avg_launch_ms': sel_ms / max(1, len(select_timing)), 'share_of_step_time': sel_ms * 1e-3 / dt},
+                                % (args.beam, VOCAB), 'launches': sel_launches,
+                                'avg_launch_ms': sel_ms / max(1, sel_launches), 'share_of_step_time': sel_ms * 1e-3 / dt},
         }
         if world == 1 and not args.no_cpu_baseline:
             result['cpu_baseline'] = cpu_baseline(args.eos_bias, args.cpu_sample)

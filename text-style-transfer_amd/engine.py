@@ -99,7 +99,7 @@ class DecodeLoop:
             self.dist_seq[:, 0] = gumbel[1]
         self.steps_done = 0
         self.rows_stepped = 0
-        self.select_log = None   # set to a list to collect (start, end, bytes) of every log-softmax/top-k launch
+        self.select_log = None   # set to a timing.LaunchTimer to time every log-softmax/top-k launch (work = bytes)
 
     def run(self, keep_logits=0):
         """Runs the loop.  Returns (out_tok [B, pos0 + T + 1], out_len [B], out_score [B]) on the device; with
@@ -137,11 +137,9 @@ class DecodeLoop:
                 if self.select_log is None:
                     K.logsoftmax_topk(logits, R, s.V, k, self.top_val, self.top_idx, self.lse)
                 else:  # measurement aid: HIP events on the launch stream around the selection pass
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
+                    self.select_log.begin()
                     K.logsoftmax_topk(logits, R, s.V, k, self.top_val, self.top_idx, self.lse)
-                    e1.record()
-                    self.select_log.append((e0, e1, float(R) * s.V * logits.element_size()))
+                    self.select_log.end(float(R) * s.V * logits.element_size())
                 K.beam_merge(self.cur, self.top_val, self.top_idx, self.lse, n_sent, k, k_in, self.eos, self.sel)
             K.retire_compact(self.cur, self.nxt, self.sel, self.lp, n_sent, k, pos0 + t, Ttot, self.eos, t == T - 1, self.top_ends,
                              self.out_tok, self.out_len, self.out_score, self.scratch, self.row_parent, self.n_alive)

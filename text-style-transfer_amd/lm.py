@@ -37,7 +37,7 @@ class TransformerLM(HipModule):
             raise ValueError("dtype must be 'fp32' or 'bf16'")
         if d % self.heads or (d // self.heads) % 4 or d % 8 or self.d_ff % 8:
             raise ValueError('model_size / n_heads must be a multiple of 4, model_size and d_ff multiples of 8')
-        self.event_log = None  # set to a list to collect (start, end, flops) of every vocabulary projection
+        self.event_log = None  # set to a timing.LaunchTimer to time every vocabulary projection (work = flops)
         s = 1.0 / math.sqrt(d)
         self._add('embed.weight', (self.V, d), std=s)
         for i in range(self.n_layers):
@@ -206,9 +206,7 @@ class TransformerLMSession:
         if log is None:
             gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
         else:  # measurement aid: HIP events on the launch stream around the vocabulary projection
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            log.begin()
             gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
-            e1.record()
-            log.append((e0, e1, 2.0 * n * d * self.V))
+            log.end(2.0 * n * d * self.V)
         return self.logits

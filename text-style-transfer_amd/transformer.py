@@ -120,7 +120,7 @@ class TransformerDecoder(HipModule):
         self.hp, self.vocab = hp, vocab
         d, V, ff = hp.d_model, len(vocab), hp.d_ff
         self.d, self.V, self.heads, self.n_layers = d, V, hp.n_heads, hp.n_layers
-        self.event_log = None  # set to a list to collect (start, end, flops) of every vocabulary projection
+        self.event_log = None  # set to a timing.LaunchTimer to time every vocabulary projection (work = flops)
         if d % hp.n_heads or (d // hp.n_heads) % 4 or d % 4:
             raise ValueError('d_model / n_heads must be a multiple of 4')
         s = 1.0 / math.sqrt(d)
@@ -281,11 +281,9 @@ class TransformerSession:
         if log is None:
             K.gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
         else:  # measurement aid: HIP events on the launch stream around the vocabulary projection
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            log.begin()
             K.gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
-            e1.record()
-            log.append((e0, e1, 2.0 * n * d * self.V))
+            log.end(2.0 * n * d * self.V)
         return self.logits
 
 
