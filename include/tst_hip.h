@@ -57,6 +57,12 @@ int tst_layernorm_f32(const float* x, const float* gamma, const float* beta, flo
 int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res,
                       int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream);
 
+/* The same product by the kernel that tst_gemm_mfma_f32 chooses for small M * N: one wave per 16 x (16 * strip) strip of
+ * C (strip = 1, 2 or 4) on v_mfma_f32_16x16x4_f32.  Same arguments, same requirements, bit-identical results (every
+ * element is the same k-ordered fma chain); exported so that tests and tuning can reach it at any size. */
+int tst_gemm_skinny_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res,
+                        int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, int strip, void* stream);
+
 /* y = LayerNorm(x) as above with the result rounded to bf16 (the operand of a following bf16 GEMM). */
 int tst_layernorm_f32_bf16(const float* x, const float* gamma, const float* beta, float eps, void* y, int64_t R, int64_t d,
                            void* stream);
@@ -189,6 +195,57 @@ int tst_retire_compact(const tst_rows* cur, const tst_rows* nxt, const int32_t* 
                        int64_t n_sent, int64_t k, int64_t step, int64_t T, int32_t eos, int last_step, int top_ends,
                        int32_t* out_tok, int32_t* out_len, float* out_score, int32_t* scratch_alive_pos,
                        int32_t* row_parent, int32_t* n_alive, void* stream);
+
+/* One decode step of a pre-norm transformer decoder stack, launched from native code: the sequence of
+ * entry points above that evaluates the model called at /root/reference/src/inference.py:132 for ONE new position
+ * (embedding, per layer: LayerNorm, q|k|v projection into the cache, self-attention, output projection + residual,
+ * [LayerNorm, q projection, cross-attention, output projection + residual,] LayerNorm, feed-forward + residual;
+ * final LayerNorm; vocabulary projection).  It adds no arithmetic of its own: results are those of the single
+ * calls.  The structs are HOST memory and only read during the call; every pointer inside is device memory.
+ * With bf16 != 0 the weights (void*) are bf16 [out][in] as for tst_gemm_mfma_bf16 and h, q, a, ff, the caches,
+ * kv_cross and logits are bf16; x, biases, LayerNorm parameters, emb, pe and z are always fp32.
+ * With bf16 == 0 the weights are fp32 [in][ld] as for tst_gemm_mfma_f32. */
+typedef struct tst_tfm_layer {
+    const float *ln_self_g, *ln_self_b;   /* LayerNorm before self-attention */
+    const void* wqkv;  const float* bqkv;  int64_t ld_wqkv;   /* fused q|k|v projection, N = 3d */
+    const void* wo;    const float* bo;    int64_t ld_wo;
+    const float *ln_cross_g, *ln_cross_b; /* cross-attention block; cwq == NULL: the layer has none */
+    const void* cwq;   const float* cbq;   int64_t ld_cwq;
+    const void* cwo;   const float* cbo;   int64_t ld_cwo;
+    const float *ln_ff_g, *ln_ff_b;
+    const void* w1;    const float* b1;    int64_t ld_w1;     /* d -> d_ff, relu */
+    const void* w2;    const float* b2;    int64_t ld_w2;     /* d_ff -> d */
+    void* cache;            /* [n_pos][slab_rows][3d] self-attention q|k|v of every position */
+    const void* kv_cross;   /* [n_sent][S][2d] k|v of the encoder outputs (cross block only) */
+} tst_tfm_layer;
+
+typedef struct tst_tfm_step {
+    int32_t n_layers, d, heads, d_ff, V, bf16;
+    int64_t n_pos, slab_rows, S, anc_ld;
+    const float* emb;       /* [V][d] */
+    const float* pe;        /* [n_pos][d] positional rows */
+    float scale;            /* embedding scale */
+    float eps;              /* LayerNorm epsilon */
+    const float* z;         /* [n_sent][d] added to the embedding of a sentence's rows, or NULL */
+    const uint8_t* mask;    /* [n_sent][S] source padding mask of the cross-attention, or NULL */
+    const float *ln_g, *ln_b;             /* final LayerNorm */
+    const void* wout;  const float* bout;  int64_t ld_wout;
+    float* x;               /* [rows][d] residual stream */
+    void *h, *q, *a;        /* [rows][d] work buffers */
+    void* ff;               /* [rows][d_ff] */
+    void* logits;           /* [rows][ld_logits] output */
+    int64_t ld_logits;
+    const tst_tfm_layer* layers;          /* host array of n_layers */
+} tst_tfm_step;
+
+#define TST_STEP_EMBED 1   /* x = emb[tok] * scale + pe[t] (+ z[sent]); without it x must hold the embeddings */
+#define TST_STEP_LAYERS 2  /* the layer stack and the final LayerNorm (into h) */
+#define TST_STEP_VOCAB 4   /* logits = h * wout + bout */
+/* Runs the phases selected in `phases` for rows 0..R-1 at position t (0 <= t < n_pos): tok [R] token ids,
+ * anc [R][anc_ld] cache rows of earlier positions, sent [R] sentence of each row.  Stops at the first failing
+ * launch and returns its code.  A caller that times the vocabulary projection calls it twice (phases 3, then 4). */
+int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const int32_t* anc, const int32_t* sent, int64_t R,
+                     int64_t t, int phases, void* stream);
 
 #ifdef __cplusplus
 }

@@ -25,11 +25,13 @@ def rs(seed):
     return np.random.RandomState(seed)
 
 
-@pytest.mark.parametrize('M,N,K_,bias,act,res', [
+GEMM_SHAPES = [
     (1, 4, 4, False, 0, False), (5, 50, 48, True, 0, False), (130, 200, 36, True, 1, False),
     (300, 1000, 256, True, 0, True), (257, 128, 1024, True, 1, True), (64, 3072, 1024, True, 0, False),
-    (1000, 768, 256, True, 0, False), (129, 129, 20, False, 1, True)])
-def test_gemm_bit_exact(K, M, N, K_, bias, act, res):
+    (1000, 768, 256, True, 0, False), (129, 129, 20, False, 1, True), (37, 90, 132, True, 0, True)]
+
+
+def _gemm_case(K, M, N, K_, bias, act, res, strip=None, odd_ldc=False):
     r = rs(M * 7 + N)
     A = r.standard_normal((M, K_)).astype(np.float32)
     W = r.standard_normal((K_, N)).astype(np.float32)
@@ -38,12 +40,29 @@ def test_gemm_bit_exact(K, M, N, K_, bias, act, res):
     ldw = (N + 3) // 4 * 4
     Wd = torch.zeros((K_, ldw), dtype=torch.float32, device='cuda')
     Wd[:, :N] = dev(W)
-    out = torch.full((M, ldw), 7.0, dtype=torch.float32, device='cuda')
-    K.gemm(dev(A), Wd[:, :N], None if b is None else dev(b), out, M, res=None if R0 is None else dev(R0), act=act)
+    ldc = ldw + (3 if odd_ldc else 0)      # an odd row stride of C: no vector stores possible
+    out = torch.full((M, ldc), 7.0, dtype=torch.float32, device='cuda')
+    K.gemm(dev(A), Wd[:, :N], None if b is None else dev(b), out, M, n_cols=N, res=None if R0 is None else dev(R0), act=act, strip=strip)
     want = C.gemm(A, W, b, R0, act)
     got = out.cpu().numpy()
     assert np.array_equal(got[:, :N], want)
     assert (got[:, N:] == 7.0).all()  # nothing written beyond column N
+
+
+@pytest.mark.parametrize('M,N,K_,bias,act,res', GEMM_SHAPES + [
+    (2100, 520, 132, True, 1, True),      # beyond the small-problem kernel: 64 x 64 tiles
+    (4100, 2000, 64, True, 0, True)])     # 128 x 128 tiles
+def test_gemm_bit_exact(K, M, N, K_, bias, act, res):
+    _gemm_case(K, M, N, K_, bias, act, res)
+
+
+@pytest.mark.parametrize('strip', [1, 2, 4])
+@pytest.mark.parametrize('M,N,K_,bias,act,res', GEMM_SHAPES)
+def test_gemm_small_problem_kernel_bit_exact(K, M, N, K_, bias, act, res, strip):
+    """The one-wave-per-strip kernel at every strip width, whatever size the dispatcher would give it."""
+    _gemm_case(K, M, N, K_, bias, act, res, strip=strip)
+    if M == 300 or M == 37:
+        _gemm_case(K, M, N, K_, bias, act, res, strip=strip, odd_ldc=True)
 
 
 def test_gemm_in_place_residual_and_row_prefix(K):

@@ -22,6 +22,33 @@ class TstRows(ctypes.Structure):
     _fields_ = [(n, c_vp) for n in ('hist', 'anc', 'sent', 'tok', 'score', 'fin', 'nemit')]
 
 
+class TstTfmLayer(ctypes.Structure):
+    """``tst_tfm_layer`` of include/tst_hip.h"""
+    _fields_ = [('ln_self_g', c_vp), ('ln_self_b', c_vp),
+                ('wqkv', c_vp), ('bqkv', c_vp), ('ld_wqkv', c_i64),
+                ('wo', c_vp), ('bo', c_vp), ('ld_wo', c_i64),
+                ('ln_cross_g', c_vp), ('ln_cross_b', c_vp),
+                ('cwq', c_vp), ('cbq', c_vp), ('ld_cwq', c_i64),
+                ('cwo', c_vp), ('cbo', c_vp), ('ld_cwo', c_i64),
+                ('ln_ff_g', c_vp), ('ln_ff_b', c_vp),
+                ('w1', c_vp), ('b1', c_vp), ('ld_w1', c_i64),
+                ('w2', c_vp), ('b2', c_vp), ('ld_w2', c_i64),
+                ('cache', c_vp), ('kv_cross', c_vp)]
+
+
+class TstTfmStep(ctypes.Structure):
+    """``tst_tfm_step`` of include/tst_hip.h"""
+    _fields_ = [('n_layers', c_i32), ('d', c_i32), ('heads', c_i32), ('d_ff', c_i32), ('V', c_i32), ('bf16', c_i32),
+                ('n_pos', c_i64), ('slab_rows', c_i64), ('S', c_i64), ('anc_ld', c_i64),
+                ('emb', c_vp), ('pe', c_vp), ('scale', c_f32), ('eps', c_f32),
+                ('z', c_vp), ('mask', c_vp), ('ln_g', c_vp), ('ln_b', c_vp),
+                ('wout', c_vp), ('bout', c_vp), ('ld_wout', c_i64),
+                ('x', c_vp), ('h', c_vp), ('q', c_vp), ('a', c_vp), ('ff', c_vp), ('logits', c_vp), ('ld_logits', c_i64),
+                ('layers', ctypes.POINTER(TstTfmLayer))]
+
+
+STEP_EMBED, STEP_LAYERS, STEP_VOCAB = 1, 2, 4
+
 _PROTOS = {
     'tst_version': ([], c_int),
     'tst_last_error': ([], ctypes.c_char_p),
@@ -29,6 +56,7 @@ _PROTOS = {
     'tst_scale_posadd_f32': ([c_vp, c_f32, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_layernorm_f32': ([c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_gemm_mfma_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp], c_int),
+    'tst_gemm_skinny_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp], c_int),
     'tst_attn_self_step_f32': ([c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_attn_cross_step_f32': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_gru_cell_step_f32': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
@@ -50,6 +78,7 @@ _PROTOS = {
     'tst_beam_merge': ([ctypes.POINTER(TstRows), c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp,
                         c_vp], c_int),
     'tst_greedy_select': ([c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(TstRows), c_vp], c_int),
+    'tst_tfm_step_run': ([ctypes.POINTER(TstTfmStep), c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp], c_int),
     'tst_retire_compact': ([ctypes.POINTER(TstRows), ctypes.POINTER(TstRows), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
                             c_i64, c_i64, c_i64, c_i32, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_int),
 }

@@ -232,24 +232,199 @@ void launch_gemm(const float* A, int64_t lda, const float* Wt, int64_t ldw, cons
 #undef TST_GEMM_LAUNCH
 }
 
+// ---- small problems -------------------------------------------------------------------------------------------------
+// With few output elements the 64 x 64 tiling leaves most of the 1024 SIMDs idle and every tile is one dependent chain of
+// K / 2 MFMAs of 64 cycles.  Here one WAVE owns a 16 x (16 * NT) strip of C and uses v_mfma_f32_16x16x4_f32 (same
+// k-ordered fmaf semantics: the four k of an instruction are accumulated in ascending order): 16 times as many independent
+// chains per output area, each K / 4 instructions of 32 cycles.  No LDS: operands go from global memory (L2 resident at
+// these sizes) to registers, KC k-values at a time, one chunk ahead of the MFMAs that use them.
+//   A: lane (r = lane & 15, kq = lane >> 4) needs A[m0 + r][4 s + kq] for MFMA step s.  It loads the float4
+//      A[m0 + r][16 c + 4 kq ..+3]; a 4 x 4 transpose over (16-lane row, register) with v_permlane32_swap and
+//      v_permlane16_swap then leaves A[m0 + r][16 c + 4 j + kq] in register j.
+//   W: the NT MFMA tiles of a strip interleave their columns: tile j owns columns n0 + NT * r + j, so the lane's
+//      operands of all tiles for one k are ONE load of NT consecutive floats of Wt, and its results are NT consecutive
+//      floats of C.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+template <int NT> struct SkVec;
+template <> struct SkVec<1> { typedef float type; };
+template <> struct SkVec<2> { typedef float2 type; };
+template <> struct SkVec<4> { typedef float4 type; };
+
+template <int NT> __device__ __forceinline__ float sk_get(const typename SkVec<NT>::type& v, int j);
+template <> __device__ __forceinline__ float sk_get<1>(const float& v, int) { return v; }
+template <> __device__ __forceinline__ float sk_get<2>(const float2& v, int j) { return j == 0 ? v.x : v.y; }
+template <> __device__ __forceinline__ float sk_get<4>(const float4& v, int j) { return j == 0 ? v.x : j == 1 ? v.y : j == 2 ? v.z : v.w; }
+
+template <int NT, bool HAS_RES, bool RELU>
+__global__ __launch_bounds__(64) void gemm_f32_skinny_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+                                                             int64_t ldw, const float* __restrict__ bias, const float* res,
+                                                             int64_t ldr, float* C, int64_t ldc, int M, int N, int K, int tiles_n,
+                                                             int vec_store) {
+    typedef typename SkVec<NT>::type wvec;
+    constexpr int KC = NT == 4 ? 64 : 128, STEPS = KC / 4;
+    const int lane = threadIdx.x, r = lane & 15, kq = lane >> 4;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * 16, n0 = tn * 16 * NT;
+    const int col0 = n0 + NT * r;                                   // first of the lane's NT columns
+    const float* a_row = A + (int64_t)min(m0 + r, M - 1) * lda;     // rows beyond M: a valid row, never stored
+    const float* w_col = W + min(col0, (int)ldw - NT);              // columns beyond ldw: valid ones, never stored
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const float b = (bias != nullptr && col0 + j < N) ? bias[col0 + j] : 0.0f;
+        acc[j] = f32x4{b, b, b, b};
+    }
+    float a_cur[STEPS], a_nxt[STEPS];
+    wvec b_cur[STEPS], b_nxt[STEPS];
+
+    // full chunk: A as float4 per 16 k (transposed in sk_mfma), W as one wvec per step
+    auto load_full = [&](float* av, wvec* bv, int k0) {
+#pragma unroll
+        for (int c = 0; c < STEPS / 4; ++c) {
+            const float4 v = *reinterpret_cast<const float4*>(a_row + k0 + 16 * c + 4 * kq);
+            av[4 * c + 0] = v.x; av[4 * c + 1] = v.y; av[4 * c + 2] = v.z; av[4 * c + 3] = v.w;
+        }
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) bv[s] = *reinterpret_cast<const wvec*>(w_col + (int64_t)(k0 + 4 * s + kq) * ldw);
+    };
+    auto mfma_full = [&](float* av, wvec* bv) {
+#pragma unroll
+        for (int c = 0; c < STEPS / 4; ++c) {
+            unsigned x0 = __float_as_uint(av[4 * c]), x1 = __float_as_uint(av[4 * c + 1]), x2 = __float_as_uint(av[4 * c + 2]),
+                     x3 = __float_as_uint(av[4 * c + 3]);
+            const auto p02 = __builtin_amdgcn_permlane32_swap(x0, x2, false, false);
+            const auto p13 = __builtin_amdgcn_permlane32_swap(x1, x3, false, false);
+            const auto q01 = __builtin_amdgcn_permlane16_swap(p02[0], p13[0], false, false);
+            const auto q23 = __builtin_amdgcn_permlane16_swap(p02[1], p13[1], false, false);
+            av[4 * c] = __uint_as_float(q01[0]); av[4 * c + 1] = __uint_as_float(q01[1]);
+            av[4 * c + 2] = __uint_as_float(q23[0]); av[4 * c + 3] = __uint_as_float(q23[1]);
+        }
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], sk_get<NT>(bv[s], j), acc[j], 0, 0, 0);
+    };
+    const int k_full = K / KC * KC;
+    if (k_full > 0) load_full(a_cur, b_cur, 0);
+    for (int k0 = 0; k0 < k_full; k0 += 2 * KC) {
+        if (k0 + KC < k_full) load_full(a_nxt, b_nxt, k0 + KC);
+        mfma_full(a_cur, b_cur);
+        if (k0 + KC < k_full) {
+            if (k0 + 2 * KC < k_full) load_full(a_cur, b_cur, k0 + 2 * KC);
+            mfma_full(a_nxt, b_nxt);
+        }
+    }
+    // the last K % KC values, four at a time: one dword of A per lane and step
+    for (int k = k_full; k < K; k += 4) {
+        const float a = a_row[k + kq];
+        const wvec b = *reinterpret_cast<const wvec*>(w_col + (int64_t)(k + kq) * ldw);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, sk_get<NT>(b, j), acc[j], 0, 0, 0);
+    }
+
+    // lane holds rows m0 + 4 kq + i (i = 0..3) of columns col0 .. col0 + NT - 1
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + 4 * kq + i;
+        if (row >= M) continue;
+        float v[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            v[j] = acc[j][i];
+            if (RELU) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
+        }
+        float* cp = C + (int64_t)row * ldc + col0;
+        if (NT > 1 && vec_store && col0 + NT <= N) {
+            if (HAS_RES) {
+                const wvec rv = *reinterpret_cast<const wvec*>(res + (int64_t)row * ldr + col0);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) v[j] = v[j] + sk_get<NT>(rv, j);
+            }
+            if (NT == 2) *reinterpret_cast<float2*>(cp) = make_float2(v[0], v[NT - 1]);
+            if (NT == 4) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1 % NT], v[2 % NT], v[3 % NT]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (col0 + j < N) {
+                    float o = v[j];
+                    if (HAS_RES) o = o + res[(int64_t)row * ldr + col0 + j];
+                    cp[j] = o;
+                }
+            }
+        }
+    }
+}
+
+template <int NT>
+void launch_skinny(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res, int64_t ldr,
+                   float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st) {
+    const int64_t tiles_m = (M + 15) / 16, tiles_n = (N + 16 * NT - 1) / (16 * NT);
+    const dim3 grid((unsigned)(tiles_m * tiles_n));
+    // NT consecutive results per lane go out as one store when C (and res) rows keep them aligned
+    const int vec_store = ldc % NT == 0 && (uintptr_t)C % (4 * NT) == 0 &&
+                          (res == nullptr || (ldr % NT == 0 && (uintptr_t)res % (4 * NT) == 0));
+#define TST_SK_LAUNCH(HR, RL)                                                                                               \
+    hipLaunchKernelGGL((gemm_f32_skinny_kernel<NT, HR, RL>), grid, dim3(64), 0, st, A, lda, Wt, ldw, bias, res, ldr, C, ldc, \
+                       (int)M, (int)N, (int)K, (int)tiles_n, vec_store)
+    switch ((res != nullptr ? 2 : 0) | (act == 1 ? 1 : 0)) {
+        case 0: TST_SK_LAUNCH(false, false); break;
+        case 1: TST_SK_LAUNCH(false, true); break;
+        case 2: TST_SK_LAUNCH(true, false); break;
+        default: TST_SK_LAUNCH(true, true); break;
+    }
+#undef TST_SK_LAUNCH
+}
+
+int check_gemm_args(const char* who, const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* res, int64_t ldr,
+                    float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act) {
+    TST_REQUIRE(A && Wt && C, TST_ERR_ARG, "%s: null pointer", who);
+    TST_REQUIRE(M >= 0 && N > 0 && K >= 4 && (act == 0 || act == 1), TST_ERR_ARG, "%s: bad sizes M=%lld N=%lld K=%lld", who, (long long)M,
+                (long long)N, (long long)K);
+    TST_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= K && ldw >= N && ldc >= N, TST_ERR_ARG,
+                "%s: K, lda, ldw must be multiples of 4 and lda >= K, ldw >= N, ldc >= N", who);
+    TST_REQUIRE(tst_aligned16(A) && tst_aligned16(Wt), TST_ERR_ARG, "%s: A and Wt must be 16-byte aligned", who);
+    TST_REQUIRE(res == nullptr || ldr >= N, TST_ERR_ARG, "%s: ldr < N", who);
+    TST_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), TST_ERR_UNSUPPORTED, "%s: size", who);
+    return TST_OK;
+}
+
 }  // namespace
+
+extern "C" int tst_gemm_skinny_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias,
+                                   const float* res, int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                                   int act, int strip, void* stream) {
+    const int rc = check_gemm_args("tst_gemm_skinny_f32", A, lda, Wt, ldw, res, ldr, C, ldc, M, N, K, act);
+    if (rc != TST_OK) return rc;
+    TST_REQUIRE(strip == 1 || strip == 2 || strip == 4, TST_ERR_ARG, "tst_gemm_skinny_f32: strip must be 1, 2 or 4");
+    if (M == 0) return TST_OK;
+    TST_REQUIRE(((M + 15) / 16) * ((N + 15) / 16) < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_skinny_f32: grid too large");
+    if (strip == 1) launch_skinny<1>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
+    else if (strip == 2) launch_skinny<2>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
+    else launch_skinny<4>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
+    return tst_after_launch("tst_gemm_skinny_f32");
+}
 
 extern "C" int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias,
                                  const float* res, int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                                  int act, void* stream) {
-    TST_REQUIRE(A && Wt && C, TST_ERR_ARG, "tst_gemm_mfma_f32: null pointer");
-    TST_REQUIRE(M >= 0 && N > 0 && K >= 4 && (act == 0 || act == 1), TST_ERR_ARG, "tst_gemm_mfma_f32: bad sizes M=%lld N=%lld K=%lld", (long long)M,
-                (long long)N, (long long)K);
-    TST_REQUIRE(K % 4 == 0 && lda % 4 == 0 && ldw % 4 == 0 && lda >= K && ldw >= N && ldc >= N, TST_ERR_ARG,
-                "tst_gemm_mfma_f32: K, lda, ldw must be multiples of 4 and lda >= K, ldw >= N, ldc >= N");
-    TST_REQUIRE(tst_aligned16(A) && tst_aligned16(Wt), TST_ERR_ARG, "tst_gemm_mfma_f32: A and Wt must be 16-byte aligned");
-    TST_REQUIRE(res == nullptr || ldr >= N, TST_ERR_ARG, "tst_gemm_mfma_f32: ldr < N");
-    TST_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_f32: size");
+    const int rc = check_gemm_args("tst_gemm_mfma_f32", A, lda, Wt, ldw, res, ldr, C, ldc, M, N, K, act);
+    if (rc != TST_OK) return rc;
     if (M == 0) return TST_OK;
     TST_REQUIRE(((M + 63) / 64) * ((N + 63) / 64) < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_f32: grid too large");
-    // 128 x 128 tiles unless they would give fewer than two workgroups per CU (256 CUs): then 64 x 64
+    // Few output elements: one wave per strip (measured crossovers on the decode shapes, in 16 x 16 tiles of C).
+    // Otherwise 128 x 128 tiles unless they would give fewer than two workgroups per CU (256 CUs): then 64 x 64.
+    const int64_t tiles16 = ((M + 15) / 16) * ((N + 15) / 16);
     const int64_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128);
-    if (big_tiles >= 4096 && N >= 2048)
+    if (tiles16 <= 768)
+        launch_skinny<1>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
+    else if (tiles16 <= 2048)
+        launch_skinny<2>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
+    else if (tiles16 <= 3072)
+        launch_skinny<4>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
+    else if (big_tiles >= 4096 && N >= 2048)
         launch_gemm<2, 4>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
     else if (big_tiles >= 512)
         launch_gemm<2, 2>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);

@@ -1,0 +1,90 @@
+// Host-side executor of one transformer decode step: the launch sequence of a whole model step issued from
+// native code in one call, so that small batches are not bound by per-launch interpreter overhead.
+// Contains no kernels; every launch goes through the single-kernel entry points of this library.
+#include "tst_common.h"
+
+namespace {
+
+struct StepCtx {
+    const tst_tfm_step* m;
+    int64_t R;
+    void* stream;
+    bool bf16;
+
+    int layernorm(const float* x, const float* g, const float* b, void* y) const {
+        return bf16 ? tst_layernorm_f32_bf16(x, g, b, m->eps, y, R, m->d, stream)
+                    : tst_layernorm_f32(x, g, b, m->eps, (float*)y, R, m->d, stream);
+    }
+    // out = epilogue(a * w + bias); out_lo: the output has the activation type (bf16 when the model is), else fp32
+    int gemm(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* res, int64_t ldr, void* out,
+             int64_t ldo, int64_t N, int64_t K, int act, bool out_lo) const {
+        return bf16 ? tst_gemm_mfma_bf16(a, lda, w, ldw, bias, res, ldr, out, ldo, R, N, K, act, out_lo ? 1 : 0, stream)
+                    : tst_gemm_mfma_f32((const float*)a, lda, (const float*)w, ldw, bias, res, ldr, (float*)out, ldo, R, N, K, act,
+                                        stream);
+    }
+};
+
+}  // namespace
+
+#define TST_TRY(expr)               \
+    do {                            \
+        const int rc_ = (expr);     \
+        if (rc_ != TST_OK) return rc_; \
+    } while (0)
+
+extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const int32_t* anc, const int32_t* sent, int64_t R,
+                                int64_t t, int phases, void* stream) {
+    TST_REQUIRE(m != nullptr && m->layers != nullptr, TST_ERR_ARG, "tst_tfm_step_run: null plan");
+    TST_REQUIRE(m->n_layers >= 1 && m->d > 0 && m->heads > 0 && m->d_ff > 0 && m->V > 0, TST_ERR_ARG, "tst_tfm_step_run: bad sizes");
+    TST_REQUIRE(R >= 0 && R <= m->slab_rows, TST_ERR_ARG, "tst_tfm_step_run: %lld rows, buffers hold %lld", (long long)R,
+                (long long)m->slab_rows);
+    TST_REQUIRE(t >= 0 && t < m->n_pos, TST_ERR_ARG, "tst_tfm_step_run: position %lld outside 0..%lld", (long long)t,
+                (long long)m->n_pos - 1);
+    TST_REQUIRE((phases & ~7) == 0 && phases != 0, TST_ERR_ARG, "tst_tfm_step_run: bad phases %d", phases);
+    TST_REQUIRE(m->x && m->h && m->a && m->ff && m->logits, TST_ERR_ARG, "tst_tfm_step_run: null work buffer");
+    if (R == 0) return TST_OK;
+    const int64_t d = m->d;
+    const StepCtx c{m, R, stream, m->bf16 != 0};
+    const int64_t esz = c.bf16 ? 2 : 4;
+
+    if (phases & TST_STEP_EMBED) {
+        TST_REQUIRE(tok && m->emb && m->pe, TST_ERR_ARG, "tst_tfm_step_run: null embedding input");
+        TST_TRY(tst_embed_posadd_f32(tok, m->emb, m->pe + t * d, nullptr, m->scale, m->x, R, d, m->V, stream));
+        if (m->z != nullptr) {
+            TST_REQUIRE(sent != nullptr, TST_ERR_ARG, "tst_tfm_step_run: z without sent");
+            TST_TRY(tst_add_rows_f32(m->x, m->z, sent, R, d, stream));
+        }
+    }
+    if (phases & TST_STEP_LAYERS) {
+        TST_REQUIRE(anc != nullptr, TST_ERR_ARG, "tst_tfm_step_run: null ancestor table");
+        for (int li = 0; li < m->n_layers; ++li) {
+            const tst_tfm_layer& L = m->layers[li];
+            TST_REQUIRE(L.cache && L.wqkv && L.wo && L.w1 && L.w2, TST_ERR_ARG, "tst_tfm_step_run: layer %d incomplete", li);
+            char* slab = (char*)L.cache + t * m->slab_rows * 3 * d * esz;   // the rows of position t
+            TST_TRY(c.layernorm(m->x, L.ln_self_g, L.ln_self_b, m->h));
+            TST_TRY(c.gemm(m->h, d, L.wqkv, L.ld_wqkv, L.bqkv, nullptr, 0, slab, 3 * d, 3 * d, d, 0, true));
+            TST_TRY(c.bf16 ? tst_attn_self_step_bf16(L.cache, m->slab_rows, anc, m->anc_ld, t, m->a, R, d, m->heads, stream)
+                           : tst_attn_self_step_f32((const float*)L.cache, m->slab_rows, anc, m->anc_ld, t, (float*)m->a, R, d,
+                                                    m->heads, stream));
+            TST_TRY(c.gemm(m->a, d, L.wo, L.ld_wo, L.bo, m->x, d, m->x, d, d, d, 0, false));
+            if (L.cwq != nullptr) {
+                TST_REQUIRE(L.kv_cross && L.cwo && m->q && sent, TST_ERR_ARG, "tst_tfm_step_run: layer %d cross block incomplete", li);
+                TST_TRY(c.layernorm(m->x, L.ln_cross_g, L.ln_cross_b, m->h));
+                TST_TRY(c.gemm(m->h, d, L.cwq, L.ld_cwq, L.cbq, nullptr, 0, m->q, d, d, d, 0, true));
+                TST_TRY(c.bf16 ? tst_attn_cross_step_bf16(m->q, L.kv_cross, m->mask, sent, m->S, m->a, R, d, m->heads, stream)
+                               : tst_attn_cross_step_f32((const float*)m->q, (const float*)L.kv_cross, m->mask, sent, m->S,
+                                                         (float*)m->a, R, d, m->heads, stream));
+                TST_TRY(c.gemm(m->a, d, L.cwo, L.ld_cwo, L.cbo, m->x, d, m->x, d, d, d, 0, false));
+            }
+            TST_TRY(c.layernorm(m->x, L.ln_ff_g, L.ln_ff_b, m->h));
+            TST_TRY(c.gemm(m->h, d, L.w1, L.ld_w1, L.b1, nullptr, 0, m->ff, m->d_ff, m->d_ff, d, 1, true));
+            TST_TRY(c.gemm(m->ff, m->d_ff, L.w2, L.ld_w2, L.b2, m->x, d, m->x, d, d, m->d_ff, 0, false));
+        }
+        TST_TRY(c.layernorm(m->x, m->ln_g, m->ln_b, m->h));
+    }
+    if (phases & TST_STEP_VOCAB) {
+        TST_REQUIRE(m->wout != nullptr, TST_ERR_ARG, "tst_tfm_step_run: null output projection");
+        TST_TRY(c.gemm(m->h, d, m->wout, m->ld_wout, m->bout, nullptr, 0, m->logits, m->ld_logits, m->V, d, 0, true));
+    }
+    return TST_OK;
+}

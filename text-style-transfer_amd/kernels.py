@@ -7,7 +7,7 @@ Where a kernel exists for fp32 and bf16 storage the wrapper picks the entry poin
 import torch
 
 from . import _lib
-from ._lib import call
+from ._lib import call, STEP_EMBED, STEP_LAYERS, STEP_VOCAB  # noqa: F401
 
 
 def _stream():
@@ -97,7 +97,7 @@ def gemm_bf16(a, w, bias, out, n_rows, n_cols=None, res=None, act=0):
          _p(out), out.stride(0), n_rows, N, K, int(act), int(out.dtype == torch.bfloat16), _stream())
 
 
-def gemm(a, wt, bias, out, n_rows, n_cols=None, res=None, act=0):
+def gemm(a, wt, bias, out, n_rows, n_cols=None, res=None, act=0, strip=None):
     """out[:n_rows, :N] = epilogue(a[:n_rows] @ wt[:, :N] + bias); ``wt`` is [K, ldw] with ldw >= N.
     ``a``, ``out`` and ``res`` may be row-strided 2-D views (unit stride in the last dimension)."""
     for t, nm in ((a, 'a'), (wt, 'wt'), (out, 'out'), (res, 'res'), (bias, 'bias')):
@@ -107,6 +107,10 @@ def gemm(a, wt, bias, out, n_rows, n_cols=None, res=None, act=0):
     N = wt.shape[1] if n_cols is None else n_cols
     assert a.shape[1] == K and out.shape[1] >= N and a.shape[0] >= n_rows and out.shape[0] >= n_rows
     assert bias is None or bias.numel() >= N
+    if strip is not None:   # the small-problem kernel, whatever the size (tests, tuning)
+        call('tst_gemm_skinny_f32', _p(a), a.stride(0), _p(wt), ldw, _p(bias), _p(res), 0 if res is None else res.stride(0),
+             _p(out), out.stride(0), n_rows, N, K, int(act), int(strip), _stream())
+        return
     call('tst_gemm_mfma_f32', _p(a), a.stride(0), _p(wt), ldw, _p(bias), _p(res), 0 if res is None else res.stride(0),
          _p(out), out.stride(0), n_rows, N, K, int(act), _stream())
 
@@ -163,6 +167,34 @@ def logsoftmax_topk(logits, n_rows, n_cols, k, top_val, top_idx, lse):
     _chk(top_val, torch.float32, 'top_val'); _chk(top_idx, torch.int32, 'top_idx'); _chk(lse, torch.float32, 'lse')
     call('tst_logsoftmax_topk' + _logits_suffix(logits), _p(logits), logits.stride(0), n_rows, n_cols, k, _p(top_val), _p(top_idx), _p(lse),
          _stream())
+
+
+class StepPlan:
+    """Host-side ``tst_tfm_step`` of one decode session: all weight, cache and work-buffer pointers of a transformer
+    decoder stack, so that a whole model step is ONE native call (``tst_tfm_step_run``).  ``layers`` is a list of dicts
+    with the keys of ``tst_tfm_layer`` holding tensors (weights with unit inner stride; their row stride is taken as
+    the leading dimension); the plan keeps every tensor alive."""
+
+    def __init__(self, *, d, heads, d_ff, V, bf16, n_pos, slab_rows, S, anc_ld, emb, pe, scale, z, mask, ln, wout, bout,
+                 x, h, q, a, ff, logits, layers, eps=1e-5):
+        self._keep = [emb, pe, z, mask, ln, wout, bout, x, h, q, a, ff, logits, layers]
+        n = len(layers)
+        self._layers = (_lib.TstTfmLayer * n)()
+        for dst, L in zip(self._layers, layers):
+            for name, _ in _lib.TstTfmLayer._fields_:
+                if name.startswith('ld_'):
+                    w = L.get(name[3:])
+                    setattr(dst, name, 0 if w is None else w.stride(0))
+                else:
+                    setattr(dst, name, _p(L.get(name)))
+        self.c = _lib.TstTfmStep(
+            n_layers=n, d=d, heads=heads, d_ff=d_ff, V=V, bf16=int(bool(bf16)), n_pos=n_pos, slab_rows=slab_rows, S=S, anc_ld=anc_ld,
+            emb=_p(emb), pe=_p(pe), scale=float(scale), eps=float(eps), z=_p(z), mask=_p(mask), ln_g=_p(ln[0]), ln_b=_p(ln[1]),
+            wout=_p(wout), bout=_p(bout), ld_wout=wout.stride(0), x=_p(x), h=_p(h), q=_p(q), a=_p(a), ff=_p(ff), logits=_p(logits),
+            ld_logits=logits.stride(0), layers=self._layers)
+
+    def run(self, rows, n_rows, t, phases):
+        call('tst_tfm_step_run', self.c, _p(rows.tok), _p(rows.anc), _p(rows.sent), n_rows, t, phases, _stream())
 
 
 class RowState:

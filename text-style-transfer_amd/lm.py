@@ -176,37 +176,46 @@ class TransformerLMSession:
         self.ff = torch.empty((R, lm.d_ff), **lo)
         self.logits = torch.empty((R, (lm.V + 7) // 8 * 8), **lo)
         self.scale = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
-        self.gemm = K.gemm_bf16 if lm.dtype == 'bf16' else K.gemm
+        self._plans = {}
 
     def reorder(self, row_parent, n_rows, identity):
         pass  # the KV cache is addressed through the ancestor table; nothing moves
 
+    def _plan(self, anc_ld):
+        """The native launch plan of a step (one per ancestor-table width)."""
+        plan = self._plans.get(anc_ld)
+        if plan is None:
+            lm, W = self.lm, self.lm.prepared()
+            layers = [dict(ln_self_g=L['ln1'][0], ln_self_b=L['ln1'][1], wqkv=L['wqkv'], bqkv=L['bqkv'], wo=L['wo'], bo=L['bo'],
+                           ln_ff_g=L['ln2'][0], ln_ff_b=L['ln2'][1], w1=L['w1'], b1=L['b1'], w2=L['w2'], b2=L['b2'],
+                           cache=self.cache[li]) for li, L in enumerate(W['layers'])]
+            plan = K.StepPlan(d=lm.d, heads=lm.heads, d_ff=lm.d_ff, V=self.V, bf16=lm.dtype == 'bf16', n_pos=self.cache[0].shape[0],
+                              slab_rows=self.R, S=0, anc_ld=anc_ld, emb=W['emb'], pe=W['pe'], scale=self.scale, z=self.z, mask=None,
+                              ln=W['ln'], wout=W['wout'], bout=W['bout'], x=self.x, h=self.h, q=None, a=self.a, ff=self.ff,
+                              logits=self.logits, layers=layers)
+            self._plans[anc_ld] = plan
+        return plan
+
     def step(self, rows, n, t, soft=None):
-        """Logits of the next token; ``soft`` (token distributions [>= n, Vp] fp32) replaces the lookup of ``rows.tok``."""
-        lm, W, gemm = self.lm, self.lm.prepared(), self.gemm
-        d, H = lm.d, lm.heads
-        x, h, a, ff = self.x, self.h, self.a, self.ff
+        """Logits of the next token; ``soft`` (token distributions [>= n, Vp] fp32) replaces the lookup of ``rows.tok``.
+        The launches of the step are issued by one native call (two when the vocabulary projection is being timed)."""
+        lm = self.lm
+        plan = self._plan(rows.anc.shape[1])
+        body = K.STEP_LAYERS
         if soft is None:
-            K.embed_posadd(rows.tok, W['emb'], W['pe'][t], self.scale, x, n)
+            body |= K.STEP_EMBED
         else:
+            W = lm.prepared()
             if 'emb_pad' not in W:
                 W['emb_pad'] = _pad_rows4(W['emb'])
-            K.soft_embed(soft, W['emb_pad'], self.scale, W['pe'][t], x, n)
-        K.add_rows(x, self.z, rows.sent, n)
-        for li, L in enumerate(W['layers']):
-            K.layernorm(x, L['ln1'][0], L['ln1'][1], h, n)
-            gemm(h, L['wqkv'], L['bqkv'], self.cache[li][t], n)
-            K.attn_self_step(self.cache[li], rows.anc, t, a, n, d, H)
-            gemm(a, L['wo'], L['bo'], x, n, res=x)
-            K.layernorm(x, L['ln2'][0], L['ln2'][1], h, n)
-            gemm(h, L['w1'], L['b1'], ff, n, act=1)
-            gemm(ff, L['w2'], L['b2'], x, n, res=x)
-        K.layernorm(x, W['ln'][0], W['ln'][1], h, n)
+            K.soft_embed(soft, W['emb_pad'], self.scale, W['pe'][t], self.x, n)
+            K.add_rows(self.x, self.z, rows.sent, n)
         log = lm.event_log
         if log is None:
-            gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
+            plan.run(rows, n, t, body | K.STEP_VOCAB)
         else:  # measurement aid: HIP events on the launch stream around the vocabulary projection
+            plan.run(rows, n, t, body)
             log.begin()
-            gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
-            log.end(2.0 * n * d * self.V)
+            plan.run(rows, n, t, K.STEP_VOCAB)
+            log.end(2.0 * n * lm.d * self.V)
         return self.logits

@@ -250,40 +250,49 @@ class TransformerSession:
         self.ff = torch.empty((R, dec.hp.d_ff), **f32)
         self.logits = torch.empty((R, (dec.V + 3) // 4 * 4), **f32)
         self.scale = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
+        self.max_len = max_len
+        self._plans = {}
 
     def reorder(self, row_parent, n_rows, identity):
         pass  # the KV cache is addressed through the ancestor table; nothing moves
 
+    def _plan(self, anc_ld):
+        """The native launch plan of a step (one per ancestor-table width)."""
+        plan = self._plans.get(anc_ld)
+        if plan is None:
+            dec, W = self.dec, self.dec.prepared()
+            layers = []
+            for li, L in enumerate(W['layers']):
+                layers.append(dict(ln_self_g=L['ln1'][0], ln_self_b=L['ln1'][1], wqkv=L['wqkv'], bqkv=L['bqkv'], wo=L['wo'], bo=L['bo'],
+                                   ln_cross_g=L['ln2'][0], ln_cross_b=L['ln2'][1], cwq=L['cwq'], cbq=L['cbq'], cwo=L['cwo'], cbo=L['cbo'],
+                                   ln_ff_g=L['ln3'][0], ln_ff_b=L['ln3'][1], w1=L['w1'], b1=L['b1'], w2=L['w2'], b2=L['b2'],
+                                   cache=self.cache[li], kv_cross=self.kv_cross[li]))
+            plan = K.StepPlan(d=dec.d, heads=dec.heads, d_ff=dec.hp.d_ff, V=self.V, bf16=False, n_pos=self.max_len, slab_rows=self.R,
+                              S=self.S, anc_ld=anc_ld, emb=W['emb'], pe=W['pe'], scale=self.scale, z=None, mask=self.mask, ln=W['ln'],
+                              wout=W['wout'], bout=W['bout'], x=self.x, h=self.h, q=self.q, a=self.a, ff=self.ff, logits=self.logits,
+                              layers=layers)
+            self._plans[anc_ld] = plan
+        return plan
+
     def step(self, rows, n, t, soft=None):
         """Logits of the next token for rows 0..n-1 at position t.  ``soft`` ([>= n, Vp] fp32 token distributions,
-        see ``kernels.soft_embed``) replaces the lookup of ``rows.tok`` by the expected embedding."""
-        dec, W = self.dec, self.dec.prepared()
-        d, H = dec.d, dec.heads
-        x, h, q, a, ff = self.x, self.h, self.q, self.a, self.ff
+        see ``kernels.soft_embed``) replaces the lookup of ``rows.tok`` by the expected embedding.  The launches of
+        the step are issued by one native call (two when the vocabulary projection is being timed)."""
+        dec = self.dec
+        plan = self._plan(rows.anc.shape[1])
+        body = K.STEP_LAYERS
         if soft is None:
-            K.embed_posadd(rows.tok, W['emb'], W['pe'][t], self.scale, x, n)
+            body |= K.STEP_EMBED
         else:
-            K.soft_embed(soft, dec.soft_embedding_matrix(), self.scale, W['pe'][t], x, n)
-        for li, L in enumerate(W['layers']):
-            K.layernorm(x, L['ln1'][0], L['ln1'][1], h, n)
-            K.gemm(h, L['wqkv'], L['bqkv'], self.cache[li][t], n)
-            K.attn_self_step(self.cache[li], rows.anc, t, a, n, d, H)
-            K.gemm(a, L['wo'], L['bo'], x, n, res=x)
-            K.layernorm(x, L['ln2'][0], L['ln2'][1], h, n)
-            K.gemm(h, L['cwq'], L['cbq'], q, n)
-            K.attn_cross_step(q, self.kv_cross[li], self.mask, rows.sent, a, n, d, H)
-            K.gemm(a, L['cwo'], L['cbo'], x, n, res=x)
-            K.layernorm(x, L['ln3'][0], L['ln3'][1], h, n)
-            K.gemm(h, L['w1'], L['b1'], ff, n, act=1)
-            K.gemm(ff, L['w2'], L['b2'], x, n, res=x)
-        K.layernorm(x, W['ln'][0], W['ln'][1], h, n)
+            K.soft_embed(soft, dec.soft_embedding_matrix(), self.scale, dec.prepared()['pe'][t], self.x, n)
         log = dec.event_log
         if log is None:
-            K.gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
+            plan.run(rows, n, t, body | K.STEP_VOCAB)
         else:  # measurement aid: HIP events on the launch stream around the vocabulary projection
+            plan.run(rows, n, t, body)
             log.begin()
-            K.gemm(h, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
-            log.end(2.0 * n * d * self.V)
+            plan.run(rows, n, t, K.STEP_VOCAB)
+            log.end(2.0 * n * dec.d * self.V)
         return self.logits
 
 

@@ -1,12 +1,13 @@
 """Throughput of the BASELINE configurations other than the one bench.py reports (they are parity-test cases;
 this script only measures them for the design notes).  One JSON line per case.
 
+  cfg1: transformer-mt (the bench.py model) at 128 / 256 sentences, greedy (not part of 'all')
   cfg3: GRU decoder (cyclegan sizes: E = H = 1024), 8192 sentences, greedy and beam 4, max_len 100,
         character vocabulary (V = 128) and a 32000-word variant
   cfg4: z-conditioned transformer LM, model_size 512, 6 layers, 8 heads, d_ff 2048, V = 32000, beam 8, bf16
         (and the same in fp32 for comparison)
 
-Usage: python tools/bench_configs.py [cfg3|cfg4|all] [--sentences N]
+Usage: python tools/bench_configs.py [cfg1|cfg3|cfg4|all] [--sentences N]
 """
 import argparse
 import json
@@ -39,6 +40,21 @@ def run(name, make_state, n_sent, repeats=3):
     print(json.dumps({'case': name, 'sentences': n_sent, 'tokens_per_s': emitted / repeats / dt, 'ms_per_batch': dt * 1e3,
                       'mean_emitted_len': emitted / repeats / n_sent, 'decode_steps': steps / repeats,
                       'row_steps': rows / repeats, 'row_steps_per_s': rows / repeats / dt}), flush=True)
+
+
+def cfg1(n_sent, bias=None):
+    """transformer-mt at the reference's own batch sizes, greedy: the launch-bound end of the path."""
+    import bench
+    dev = torch.device('cuda', 0)
+    model, vocab = bench.build_model(dev, 5.5 if bias is None else bias)
+    for B in sorted({128, 256, n_sent}):
+        src = synthetic.multi30k_like_sources(B, bench.VOCAB, seed=1235).to(dev)
+
+        def make():
+            encs, mask = model.encoder(src)
+            return tst_amd.InferenceState({'model': model.decoder, 'inputs': encs, 'enc_mask': mask, 'vocab': vocab,
+                                           'max_len': bench.MAX_LEN})
+        run('cfg1 transformer-mt V=32000 greedy fp32 max_len=50 (encoder included)', make, B, repeats=5)
 
 
 def cfg3(n_sent, bias=None):
@@ -78,6 +94,8 @@ if __name__ == '__main__':
     ap.add_argument('--dtype', default=None, help='cfg4: only this dtype (bf16 or fp32)')
     ap.add_argument('--eos-bias', type=float, default=None, help='override the calibrated EOS bias (calibration runs)')
     a = ap.parse_args()
+    if a.which == 'cfg1':
+        cfg1(a.sentences, a.eos_bias)
     if a.which in ('cfg3', 'all'):
         cfg3(a.sentences, a.eos_bias)
     if a.which in ('cfg4', 'all'):
