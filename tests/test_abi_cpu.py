@@ -41,6 +41,19 @@ def test_argument_errors_are_reported_not_crashed():
         _lib.call('tst_gemm_mfma_f32', 16, 6, 16, 4, None, None, 0, 16, 4, 1, 4, 6, 0, None)
     with pytest.raises(_lib.TstError, match='1 <= k'):
         _lib.call('tst_logsoftmax_topk_f32', 16, 100, 1, 100, 9, 16, 16, 16, None)
+    with pytest.raises(_lib.TstError, match='strip must be'):
+        _lib.call('tst_gemm_skinny_f32', 16, 4, 16, 4, None, None, 0, 16, 4, 1, 4, 4, 0, 3, None)
+    # the whole-step launcher checks its plan before the first launch
+    with pytest.raises(_lib.TstError, match='null plan'):
+        _lib.call('tst_tfm_step_run', None, None, None, None, 1, 0, 7, None)
+    layers = (_lib.TstTfmLayer * 1)()
+    plan = _lib.TstTfmStep(n_layers=1, d=8, heads=2, d_ff=16, V=10, n_pos=4, slab_rows=2, layers=layers)
+    with pytest.raises(_lib.TstError, match='buffers hold 2'):
+        _lib.call('tst_tfm_step_run', plan, None, None, None, 3, 0, 7, None)
+    with pytest.raises(_lib.TstError, match='position 4 outside'):
+        _lib.call('tst_tfm_step_run', plan, None, None, None, 2, 4, 7, None)
+    with pytest.raises(_lib.TstError, match='bad phases'):
+        _lib.call('tst_tfm_step_run', plan, None, None, None, 2, 0, 8, None)
 
 
 def test_no_product_module_touches_the_oracle():
