@@ -95,6 +95,14 @@ int tst_attn_self_step_f32(const float* cache, int64_t slab_rows, const int32_t*
 int tst_attn_cross_step_f32(const float* q, const float* kv, const uint8_t* mask, const int32_t* sent, int64_t S,
                             float* out, int64_t R, int64_t d, int64_t heads, void* stream);
 
+/* tst_attn_cross_step_f32 over a PACKED k|v: kv [n_packed][2*d] holds only the unmasked source positions, and
+ * kvrow [n_sent][S] gives the row of kv for position p of sentence s (read only where mask is non-zero).  Scores,
+ * softmax and value sum are those of the padded form (positions keep their numbers), so results are identical; what
+ * changes is that no k|v row has to exist for a padding position.  Used by the encoder pass
+ * (/root/reference/src/trainers/transformer_mt_trainer.py:91), which then computes nothing for padding. */
+int tst_attn_cross_packed_f32(const float* q, const float* kv, const uint8_t* mask, const int32_t* sent, const int32_t* kvrow,
+                              int64_t S, float* out, int64_t R, int64_t d, int64_t heads, void* stream);
+
 /* The two attention steps with bf16 cache / q / k|v / output (same layouts, 2-byte elements); scores,
  * softmax and the value sum are computed in fp32 in the same order as the fp32 kernels. */
 int tst_attn_self_step_bf16(const void* cache, int64_t slab_rows, const int32_t* anc, int64_t anc_ld, int64_t pos,
@@ -228,6 +236,8 @@ typedef struct tst_tfm_step {
     float eps;              /* LayerNorm epsilon */
     const float* z;         /* [n_sent][d] added to the embedding of a sentence's rows, or NULL */
     const uint8_t* mask;    /* [n_sent][S] source padding mask of the cross-attention, or NULL */
+    const int32_t* kvrow;   /* NULL: kv_cross is [n_sent][S][2d]; else kv_cross is packed and this is its
+                               [n_sent][S] row map (tst_attn_cross_packed_f32; fp32 only, needs mask) */
     const float *ln_g, *ln_b;             /* final LayerNorm */
     const void* wout;  const float* bout;  int64_t ld_wout;
     float* x;               /* [rows][d] residual stream */

@@ -201,7 +201,10 @@ def test_whole_prefix_call_and_encoder(T):
     encs, enc_mask = model.encoder(src.cuda())
     assert np.array_equal(enc_mask.cpu().numpy(), fx['enc_mask'])
     want, _ = C.CanonTransformerEncoder(tmodel.encoder, cfg['hp']['n_heads'])(fx['src'])
-    assert np.array_equal(encs.cpu().numpy(), want)
+    live = fx['enc_mask'][:, 0, :].astype(bool)
+    assert not live.all()                                          # the fixture has padding
+    assert np.array_equal(encs.cpu().numpy()[live], want[live])    # every real position, bit for bit
+    assert (encs.cpu().numpy()[~live] == 0).all()                  # padding positions are not computed
     valid = fx['enc_mask'][:, 0, :]
     ok, err = logits_close(encs.cpu().numpy()[valid], fx['encs'][valid])
     assert ok, err
@@ -214,6 +217,35 @@ def test_whole_prefix_call_and_encoder(T):
     # end to end through the product's own encoder: same tokens as the reference fixture
     st = T.InferenceState({'model': model.decoder, 'inputs': encs, 'enc_mask': enc_mask, 'vocab': vocab, 'max_len': cfg['max_len']})
     assert seqs_of(st.inference()) == fx['seqs']
+
+
+def test_encoder_computes_only_real_positions_wherever_the_padding_is(T):
+    """Padding inside and in front of a sentence (the mask is ``src != pad``, not a length): the packed rows keep their
+    position numbers, so every real position equals the canonical padded computation bit for bit."""
+    fx = load_fixture('tfm_v1000')
+    cfg = fx['config']
+    tmodel, model, vocab = native_models(T, cfg)
+    pad = vocab.stoi['<pad>']
+    src = fx['src'].copy()
+    src[0, 1] = pad
+    src[1, 0] = pad
+    src[2, 2:4] = pad
+    encs, enc_mask = model.encoder(torch.from_numpy(src).long().cuda())
+    live = src != pad
+    assert np.array_equal(enc_mask.cpu().numpy()[:, 0, :], live)
+    want, _ = C.CanonTransformerEncoder(tmodel.encoder, cfg['hp']['n_heads'])(src)
+    assert np.array_equal(encs.cpu().numpy()[live], want[live])
+    assert (encs.cpu().numpy()[~live] == 0).all()
+    # a batch without any padding, and one sentence of one token
+    full = np.random.RandomState(4).randint(4, cfg['V'], size=(3, 6)).astype(np.int32)
+    encs, _ = model.encoder(torch.from_numpy(full).long().cuda())
+    want, _ = C.CanonTransformerEncoder(tmodel.encoder, cfg['hp']['n_heads'])(full)
+    assert np.array_equal(encs.cpu().numpy(), want)
+    one = np.full((1, 5), pad, dtype=np.int32)
+    one[0, 0] = 7
+    encs, _ = model.encoder(torch.from_numpy(one).long().cuda())
+    want, _ = C.CanonTransformerEncoder(tmodel.encoder, cfg['hp']['n_heads'])(one)
+    assert np.array_equal(encs.cpu().numpy()[0, 0], want[0, 0])
 
 
 def test_stack_finished_and_errors(T):

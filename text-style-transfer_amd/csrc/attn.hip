@@ -38,6 +38,7 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
     int64_t R, int d, int heads, int dh, float scale) {
     __shared__ float sc[4][MAXP];   // score, then softmax weight, per position
     __shared__ int slot[4][MAXP];   // SELF: cache row of every position; else: the list of unmasked positions
+    __shared__ int kvr[4][MAXP];    // cross: the k|v row of every listed position
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     int64_t gw = (int64_t)blockIdx.x * 4 + w;
     const int64_t total = R * heads;
@@ -63,8 +64,11 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
             const int p = p0 + lane;
             const bool live = p < n && (mask == nullptr || mask[ent * n + p] != 0);
             const unsigned long long bal = __ballot(live);
-            if (live) slot[w][nl + __popcll(bal & ((1ull << lane) - 1ull))] = p;
-            else if (p < n) sc[w][p] = -INFINITY;
+            if (live) {
+                const int at = nl + __popcll(bal & ((1ull << lane) - 1ull));
+                slot[w][at] = p;
+                kvr[w][at] = anc != nullptr ? anc[ent * n + p] : (int)(ent * n + p);   // anc: optional row map of a packed k|v
+            } else if (p < n) sc[w][p] = -INFINITY;
             nl += __popcll(bal);
         }
     }
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
     // key row of the i-th live position; the value row follows d elements later
     auto krow = [&](int i) -> const T* {
         if (SELF) return base + (int64_t)i * slab_stride + (int64_t)slot[w][i] * 3 * d + d + h * dh;
-        return base + (ent * n + slot[w][i]) * 2 * (int64_t)d + h * dh;
+        return base + (int64_t)kvr[w][i] * 2 * d + h * dh;
     };
 
     // scores: 16 lanes per position, 4 positions per pass, 4 passes in flight (independent loads)
@@ -195,6 +199,7 @@ __global__ __launch_bounds__(256) void attn_step_h64_kernel(
     int64_t R, int d, int heads, float scale) {
     __shared__ float sc[4][4][MAXP];   // [wave][head of the group][position]: score, then softmax weight
     __shared__ int slot[4][MAXP];      // SELF: cache row of every position; else: the list of unmasked positions
+    __shared__ int kvr[4][MAXP];       // cross: the k|v row of every listed position
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int hgroups = heads >> 2;
     int64_t gw = (int64_t)blockIdx.x * 4 + w;
@@ -220,8 +225,11 @@ __global__ __launch_bounds__(256) void attn_step_h64_kernel(
             const int p = p0 + lane;
             const bool live = p < n && (mask == nullptr || mask[ent * n + p] != 0);
             const unsigned long long bal = __ballot(live);
-            if (live) slot[w][nl + __popcll(bal & ((1ull << lane) - 1ull))] = p;
-            else if (p < n) { sc[w][0][p] = -INFINITY; sc[w][1][p] = -INFINITY; sc[w][2][p] = -INFINITY; sc[w][3][p] = -INFINITY; }
+            if (live) {
+                const int at = nl + __popcll(bal & ((1ull << lane) - 1ull));
+                slot[w][at] = p;
+                kvr[w][at] = anc != nullptr ? anc[ent * n + p] : (int)(ent * n + p);
+            } else if (p < n) { sc[w][0][p] = -INFINITY; sc[w][1][p] = -INFINITY; sc[w][2][p] = -INFINITY; sc[w][3][p] = -INFINITY; }
             nl += __popcll(bal);
         }
     }
@@ -230,7 +238,7 @@ __global__ __launch_bounds__(256) void attn_step_h64_kernel(
 
     auto krow = [&](int i) -> const T* {   // this lane's 4 key elements of the i-th live position; values d further
         if (SELF) return base + (int64_t)i * slab_stride + (int64_t)slot[w][i] * 3 * d + d + eoff;
-        return base + (ent * n + slot[w][i]) * 2 * (int64_t)d + eoff;
+        return base + (int64_t)kvr[w][i] * 2 * d + eoff;
     };
 
     for (int i0 = 0; i0 < nl; i0 += 8) {   // 8 positions in flight
@@ -364,6 +372,19 @@ extern "C" int tst_attn_cross_step_f32(const float* q, const float* kv, const ui
     if (R == 0) return TST_OK;
     return launch_attn<float, false>(kv, 0, nullptr, 0, q, mask, sent, S, out, R, d, heads, (hipStream_t)stream,
                               "tst_attn_cross_step_f32");
+}
+
+extern "C" int tst_attn_cross_packed_f32(const float* q, const float* kv, const uint8_t* mask, const int32_t* sent,
+                                         const int32_t* kvrow, int64_t S, float* out, int64_t R, int64_t d, int64_t heads,
+                                         void* stream) {
+    TST_REQUIRE(q && kv && sent && out && kvrow, TST_ERR_ARG, "tst_attn_cross_packed_f32: null pointer");
+    TST_REQUIRE(R >= 0 && d > 0 && heads > 0 && d % heads == 0 && (d / heads) % 4 == 0 && S > 0, TST_ERR_ARG,
+                "tst_attn_cross_packed_f32: bad sizes");
+    TST_REQUIRE(S <= MAXP, TST_ERR_UNSUPPORTED, "tst_attn_cross_packed_f32: at most %d source positions", MAXP);
+    TST_REQUIRE(tst_aligned16(q) && tst_aligned16(kv) && tst_aligned16(out), TST_ERR_ARG, "tst_attn_cross_packed_f32: alignment");
+    if (R == 0) return TST_OK;
+    return launch_attn<float, false>(kv, 0, kvrow, 0, q, mask, sent, S, out, R, d, heads, (hipStream_t)stream,
+                              "tst_attn_cross_packed_f32");
 }
 
 // bf16 storage (cache, q, k|v and output), fp32 arithmetic in the same order as the fp32 kernels

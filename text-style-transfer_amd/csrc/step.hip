@@ -71,9 +71,15 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
                 TST_REQUIRE(L.kv_cross && L.cwo && m->q && sent, TST_ERR_ARG, "tst_tfm_step_run: layer %d cross block incomplete", li);
                 TST_TRY(c.layernorm(m->x, L.ln_cross_g, L.ln_cross_b, m->h));
                 TST_TRY(c.gemm(m->h, d, L.cwq, L.ld_cwq, L.cbq, nullptr, 0, m->q, d, d, d, 0, true));
-                TST_TRY(c.bf16 ? tst_attn_cross_step_bf16(m->q, L.kv_cross, m->mask, sent, m->S, m->a, R, d, m->heads, stream)
-                               : tst_attn_cross_step_f32((const float*)m->q, (const float*)L.kv_cross, m->mask, sent, m->S,
-                                                         (float*)m->a, R, d, m->heads, stream));
+                if (m->kvrow != nullptr) {
+                    TST_REQUIRE(!c.bf16 && m->mask != nullptr, TST_ERR_ARG, "tst_tfm_step_run: a packed k|v needs fp32 and a mask");
+                    TST_TRY(tst_attn_cross_packed_f32((const float*)m->q, (const float*)L.kv_cross, m->mask, sent, m->kvrow, m->S,
+                                                      (float*)m->a, R, d, m->heads, stream));
+                } else {
+                    TST_TRY(c.bf16 ? tst_attn_cross_step_bf16(m->q, L.kv_cross, m->mask, sent, m->S, m->a, R, d, m->heads, stream)
+                                   : tst_attn_cross_step_f32((const float*)m->q, (const float*)L.kv_cross, m->mask, sent, m->S,
+                                                             (float*)m->a, R, d, m->heads, stream));
+                }
                 TST_TRY(c.gemm(m->a, d, L.cwo, L.ld_cwo, L.cbo, m->x, d, m->x, d, d, d, 0, false));
             }
             TST_TRY(c.layernorm(m->x, L.ln_ff_g, L.ln_ff_b, m->h));

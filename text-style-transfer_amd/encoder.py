@@ -1,9 +1,9 @@
 """Transformer encoder on the HIP kernels: the pass that produces the decode loop's ``inputs``
 (``encs, enc_mask = transformer.encoder(src)``, ``/root/reference/src/trainers/transformer_mt_trainer.py:91``).
 
-Pre-norm layers as in the decoder.  Self-attention over a whole padded sentence reuses the one-query
-attention kernel: every (sentence, position) is a row whose keys/values are the S positions of its own
-sentence, with the padding mask applied to the keys.
+Pre-norm layers as in the decoder.  Self-attention over a sentence reuses the one-query attention kernel:
+every non-padding (sentence, position) is a row whose keys/values are the non-padding positions of its own
+sentence.
 """
 import math
 from collections import OrderedDict
@@ -62,33 +62,42 @@ class TransformerEncoder(HipModule):
         return self._prepared
 
     def __call__(self, src):
-        """src [B,S] token ids -> (encs [B,S,d] fp32, enc_mask [B,1,S] bool; True where src is not padding)."""
+        """src [B,S] token ids -> (encs [B,S,d] fp32, enc_mask [B,1,S] bool; True where src is not padding).
+        Only the non-padding positions are computed (rows packed sentence after sentence; a batch padded to its
+        longest sentence is mostly padding); ``encs`` is zero at padding positions, which nothing downstream reads."""
         W, dev, d = self.prepared(), self.device, self.d
         src = src.to(dev)
         B, S = src.shape
         if S > W['pe'].shape[0]:
             raise ValueError('source length %d exceeds pe_max_len %d' % (S, W['pe'].shape[0]))
-        n = B * S
         enc_mask = (src != self.pad_idx)
-        mask8 = enc_mask.to(torch.uint8).contiguous()
+        flat = enc_mask.reshape(-1)
+        idx = flat.nonzero().squeeze(1)                       # packed row -> padded row, ascending
+        n = int(idx.numel())
         f32 = dict(dtype=torch.float32, device=dev)
+        encs = torch.zeros((B * S, d), **f32)
+        if n == 0:
+            return encs.view(B, S, d), enc_mask.unsqueeze(1)
+        mask8 = enc_mask.to(torch.uint8).contiguous()
+        kvrow = (torch.cumsum(flat, 0, dtype=torch.int32) - 1).view(B, S).contiguous()   # padded row -> packed row
+        tok = src.reshape(-1)[idx].to(torch.int32)
+        pos = (idx % S).to(torch.int32)
+        sent = (idx // S).to(torch.int32)
         x = torch.empty((n, d), **f32)
         h, q, a = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-        kv = torch.empty((B, S, 2 * d), **f32)
+        kv = torch.empty((n, 2 * d), **f32)
         ff = torch.empty((n, self.hp.d_ff), **f32)
-        tok = src.to(torch.int32).contiguous().view(-1)
-        sent = torch.arange(B, dtype=torch.int32, device=dev).repeat_interleave(S)
         scale = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
-        pos = torch.arange(S, dtype=torch.int32, device=dev).repeat(B)
         K.embed_posadd(tok, W['emb'], W['pe'], scale, x, n, pos=pos)
         for L in W['layers']:
             K.layernorm(x, L['ln1'][0], L['ln1'][1], h, n)
             K.gemm(h, L['wq'], L['bq'], q, n)
-            K.gemm(h, L['wkv'], L['bkv'], kv.view(n, 2 * d), n)
-            K.attn_cross_step(q, kv, mask8, sent, a, n, d, self.heads)
+            K.gemm(h, L['wkv'], L['bkv'], kv, n)
+            K.attn_cross_step(q, kv, mask8, sent, a, n, d, self.heads, kvrow=kvrow)
             K.gemm(a, L['wo'], L['bo'], x, n, res=x)
             K.layernorm(x, L['ln2'][0], L['ln2'][1], h, n)
             K.gemm(h, L['w1'], L['b1'], ff, n, act=1)
             K.gemm(ff, L['w2'], L['b2'], x, n, res=x)
         K.layernorm(x, W['ln'][0], W['ln'][1], h, n)
-        return h.view(B, S, d), enc_mask.unsqueeze(1)
+        encs.index_copy_(0, idx, h)
+        return encs.view(B, S, d), enc_mask.unsqueeze(1)

@@ -123,11 +123,17 @@ def attn_self_step(cache, anc, pos, out, n_rows, d, heads):
     call('tst_attn_self_step_bf16' if cache.dtype == torch.bfloat16 else 'tst_attn_self_step_f32', _p(cache), cache.shape[1], _p(anc), anc.shape[1], pos, _p(out), n_rows, d, heads, _stream())
 
 
-def attn_cross_step(q, kv, mask, sent, out, n_rows, d, heads):
-    """q [rows, d]; kv [n_sent, S, 2d]; mask [n_sent, S] uint8 or None; sent [rows] int32"""
+def attn_cross_step(q, kv, mask, sent, out, n_rows, d, heads, kvrow=None):
+    """q [rows, d]; kv [n_sent, S, 2d]; mask [n_sent, S] uint8 or None; sent [rows] int32.
+    With ``kvrow`` ([n_sent, S] int32) ``kv`` is packed, [n_packed, 2d]: the row of (sentence, position) is kvrow[s, p]."""
     dt = torch.bfloat16 if q.dtype == torch.bfloat16 else torch.float32
     _chk(q, dt, 'q'); _chk(kv, dt, 'kv'); _chk(mask, torch.uint8, 'mask'); _chk(sent, torch.int32, 'sent')
     _chk(out, dt, 'out')
+    if kvrow is not None:
+        _chk(kvrow, torch.int32, 'kvrow')
+        assert dt == torch.float32 and mask is not None and tuple(kvrow.shape) == tuple(mask.shape) and kv.shape[-1] == 2 * d
+        call('tst_attn_cross_packed_f32', _p(q), _p(kv), _p(mask), _p(sent), _p(kvrow), mask.shape[1], _p(out), n_rows, d, heads, _stream())
+        return
     assert kv.shape[2] == 2 * d and (mask is None or tuple(mask.shape) == tuple(kv.shape[:2]))
     call('tst_attn_cross_step_bf16' if dt == torch.bfloat16 else 'tst_attn_cross_step_f32', _p(q), _p(kv), _p(mask), _p(sent), kv.shape[1], _p(out), n_rows, d, heads, _stream())
 
@@ -176,8 +182,8 @@ class StepPlan:
     the leading dimension); the plan keeps every tensor alive."""
 
     def __init__(self, *, d, heads, d_ff, V, bf16, n_pos, slab_rows, S, anc_ld, emb, pe, scale, z, mask, ln, wout, bout,
-                 x, h, q, a, ff, logits, layers, eps=1e-5):
-        self._keep = [emb, pe, z, mask, ln, wout, bout, x, h, q, a, ff, logits, layers]
+                 x, h, q, a, ff, logits, layers, eps=1e-5, kvrow=None):
+        self._keep = [kvrow, emb, pe, z, mask, ln, wout, bout, x, h, q, a, ff, logits, layers]
         n = len(layers)
         self._layers = (_lib.TstTfmLayer * n)()
         for dst, L in zip(self._layers, layers):
@@ -189,7 +195,7 @@ class StepPlan:
                     setattr(dst, name, _p(L.get(name)))
         self.c = _lib.TstTfmStep(
             n_layers=n, d=d, heads=heads, d_ff=d_ff, V=V, bf16=int(bool(bf16)), n_pos=n_pos, slab_rows=slab_rows, S=S, anc_ld=anc_ld,
-            emb=_p(emb), pe=_p(pe), scale=float(scale), eps=float(eps), z=_p(z), mask=_p(mask), ln_g=_p(ln[0]), ln_b=_p(ln[1]),
+            emb=_p(emb), pe=_p(pe), scale=float(scale), eps=float(eps), z=_p(z), mask=_p(mask), kvrow=_p(kvrow), ln_g=_p(ln[0]), ln_b=_p(ln[1]),
             wout=_p(wout), bout=_p(bout), ld_wout=wout.stride(0), x=_p(x), h=_p(h), q=_p(q), a=_p(a), ff=_p(ff), logits=_p(logits),
             ld_logits=logits.stride(0), layers=self._layers)
 

@@ -237,11 +237,22 @@ class TransformerSession:
         self.mask = _normalise_mask(enc_mask, B, S, dev)
         f32 = dict(dtype=torch.float32, device=dev)
         flat = encs.view(B * S, d)
+        # k|v of the encoder outputs, for the non-padding source positions only: rows packed sentence after sentence,
+        # kvrow[sentence, position] = packed row (a batch padded to its longest sentence is mostly padding)
+        self.kvrow = None
+        n_src = B * S
+        if self.mask is not None:
+            live = self.mask.view(-1) != 0
+            idx = live.nonzero().squeeze(1)
+            if 0 < idx.numel() < B * S:
+                self.kvrow = (torch.cumsum(live, 0, dtype=torch.int32) - 1).view(B, S).contiguous()
+                flat = flat.index_select(0, idx)
+                n_src = int(idx.numel())
         self.kv_cross = []
         for L in W['layers']:
-            kv = torch.empty((B, S, 2 * d), **f32)
-            K.gemm(flat, L['cwkv'], L['cbkv'], kv.view(B * S, 2 * d), B * S)
-            self.kv_cross.append(kv)
+            kv = torch.empty((n_src, 2 * d), **f32)
+            K.gemm(flat, L['cwkv'], L['cbkv'], kv, n_src)
+            self.kv_cross.append(kv if self.kvrow is not None else kv.view(B, S, 2 * d))
         self.cache = [torch.empty((max_len, R, 3 * d), **f32) for _ in W['layers']]
         self.x = torch.empty((R, d), **f32)
         self.h = torch.empty((R, d), **f32)
@@ -268,7 +279,8 @@ class TransformerSession:
                                    ln_ff_g=L['ln3'][0], ln_ff_b=L['ln3'][1], w1=L['w1'], b1=L['b1'], w2=L['w2'], b2=L['b2'],
                                    cache=self.cache[li], kv_cross=self.kv_cross[li]))
             plan = K.StepPlan(d=dec.d, heads=dec.heads, d_ff=dec.hp.d_ff, V=self.V, bf16=False, n_pos=self.max_len, slab_rows=self.R,
-                              S=self.S, anc_ld=anc_ld, emb=W['emb'], pe=W['pe'], scale=self.scale, z=None, mask=self.mask, ln=W['ln'],
+                              S=self.S, anc_ld=anc_ld, emb=W['emb'], pe=W['pe'], scale=self.scale, z=None, mask=self.mask, kvrow=self.kvrow,
+                              ln=W['ln'],
                               wout=W['wout'], bout=W['bout'], x=self.x, h=self.h, q=self.q, a=self.a, ff=self.ff, logits=self.logits,
                               layers=layers)
             self._plans[anc_ld] = plan
