@@ -28,7 +28,8 @@ extern "C" {
 #define TST_ERR_LAUNCH (-2)      /* the HIP runtime refused the launch */
 #define TST_ERR_UNSUPPORTED (-3) /* shape outside what the kernel was built for */
 
-/* ABI version of this header (major * 100 + minor). */
+/* ABI version of this header (major * 100 + minor): 101 = 100 + tst_gemm_skinny_f32, tst_attn_cross_packed_f32,
+ * tst_tfm_step_run (additions only). */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
