@@ -408,6 +408,17 @@ def generator(torch_module, z):
     return h
 
 
+def ffn(torch_module, x):
+    """``oracle.torch_ref.FFN`` in canonical arithmetic (k-ordered fma chains; widths padded with zeros to a multiple
+    of 4 add only fma(0, 0, acc) terms, which change nothing)."""
+    h = np.ascontiguousarray(np.asarray(x, np.float32))
+    n = len(torch_module.layers)
+    for i, layer in enumerate(torch_module.layers):
+        w = layer.weight.detach().numpy().astype(np.float32)
+        h = gemm(h, np.ascontiguousarray(w.T), layer.bias.detach().numpy().astype(np.float32), None, 0 if i == n - 1 else 1)
+    return h
+
+
 class _GRUSession:
     def __init__(self, m, h):
         self.m, self.h = m, [np.ascontiguousarray(h[i]) for i in range(h.shape[0])]

@@ -336,6 +336,23 @@ class Generator(nn.Module):
         return self.gru(x, z.unsqueeze(0))[1].squeeze(0)
 
 
+class FFN(nn.Module):
+    """Specification of ``FFN(sizes)`` as the pre-decode path uses it (``merge_z`` at
+    ``/root/reference/src/prod/style_model.py:40,67``): linear layers, ReLU between them, none after the last.  The
+    reference's class is in the absent model-zoo submodule; the one-layer form is a linear map under any choice."""
+
+    def __init__(self, sizes, dropout=0.0):
+        super().__init__()
+        self.layers = nn.ModuleList([nn.Linear(a, b) for a, b in zip(sizes[:-1], sizes[1:])])
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = layer(x)
+            if i + 1 < len(self.layers):
+                x = torch.relu(x)
+        return x
+
+
 class RNNLM(nn.Module):
     """Multi-layer GRU language model with carried state ``z [n_layers, B, size]``; constructor as at
     ``/root/reference/src/prod/dialog_model.py:49``: ``RNNLM(size, vocab, n_layers=...)``."""

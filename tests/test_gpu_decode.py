@@ -442,3 +442,42 @@ def test_embed_and_gru_submodules_as_the_prod_callers_use_them(T):
     for t in range(ids.shape[1]):
         sess.step(ids[:, t].numpy().astype(np.int32), t)
     assert np.array_equal(h_n.cpu().numpy(), np.stack(sess.h))
+
+
+def test_ffn_and_the_style_model_pre_decode_sequence(T):
+    """``merge_z = FFN([H + n_morphs, H])`` and the sequence of /root/reference/src/prod/style_model.py:64-69:
+    z = encoder(src); z = merge_z(cat([z, morphs])); z = decoder.gru(decoder.embed(first_chars), z.unsqueeze(0))[1];
+    simple_inference(decoder, z, ...).  FFN bit for bit against the canonical oracle (odd input width: 64 + 23),
+    the decoded ids against the reference loop restated on the specification modules."""
+    from oracle import torch_ref as R
+    V, H, n_morphs = 60, 64, 23
+    tv = R.synthetic_vocab(V)
+    vocab = T.Vocab.synthetic(V)
+    torch.manual_seed(11)
+    enc_t, ffn_t, ffn3_t = R.RNNEncoder(H, H, tv), R.FFN([H + n_morphs, H]), R.FFN([H + n_morphs, 40, 30, H])
+    dec_t = R.synthetic_init(R.RNNDecoder(H, H, tv), tv.stoi['<eos>'], 1.0, 2.0, seed=5)
+    enc, ffn, ffn3, dec = T.RNNEncoder(H, H, vocab), T.FFN([H + n_morphs, H]), T.FFN([H + n_morphs, 40, 30, H]), T.RNNDecoder(H, H, vocab)
+    for mine, theirs in ((enc, enc_t), (ffn, ffn_t), (ffn3, ffn3_t), (dec, dec_t)):
+        mine.load_state_dict(theirs.state_dict())
+    r = np.random.RandomState(6)
+    src = torch.from_numpy(r.randint(4, V, size=(21, 7)))
+    first = torch.from_numpy(r.randint(4, V, size=(21, 3)))
+    morphs = torch.from_numpy((r.random_sample((21, n_morphs)) < 0.2).astype(np.float32))
+    z = enc(src.cuda())
+    x = torch.cat([z, morphs.cuda()], dim=1)
+    merged = ffn(x)
+    assert np.array_equal(merged.cpu().numpy(), C.ffn(ffn_t, x.cpu().numpy()))
+    assert np.array_equal(ffn3(x).cpu().numpy(), C.ffn(ffn3_t, x.cpu().numpy()))          # hidden layers with ReLU
+    with torch.no_grad():
+        ok, err = logits_close(ffn3(x).cpu().numpy(), ffn3_t(x.cpu()).numpy())
+        assert ok, err
+    z2 = dec.gru(dec.embed(first.cuda()), merged.unsqueeze(0))[1].squeeze(0)
+    got = T.simple_inference(dec, z2, vocab, max_len=12)
+    with torch.no_grad():
+        zt = ffn_t(torch.cat([enc_t(src), morphs], dim=1))
+        zt = dec_t.gru(dec_t.embed(first), zt.unsqueeze(0))[1].squeeze(0)
+        ok, err = logits_close(z2.cpu().numpy(), zt.numpy())
+        assert ok, err
+        want = R.ref_simple_inference(dec_t, z2.cpu(), tv, max_len=12)
+    assert got == want
+    assert len(got) == 21 and any(len(g) < 13 for g in got)

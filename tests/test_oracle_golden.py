@@ -181,6 +181,16 @@ def ensemble_torch_model(cfg):
     return R.WeightedLMEnsemble(members, cfg['weights']).eval(), members, vocab
 
 
+def test_canonical_ffn_close_to_torch():
+    torch.manual_seed(2)
+    m = R.FFN([87, 40, 64])
+    x = np.random.RandomState(1).standard_normal((9, 87)).astype(np.float32)
+    with torch.no_grad():
+        want = m(torch.from_numpy(x)).numpy()
+    ok, err = logits_close(C.ffn(m, x), want)
+    assert ok, err
+
+
 def test_ensemble_restatement_matches_reference_fixture():
     """``oracle.torch_ref.WeightedLMEnsemble`` under the restated loop against the real class under the real loop."""
     fx = load_fixture('ensemble_rnnlm')

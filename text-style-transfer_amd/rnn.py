@@ -334,3 +334,53 @@ class Generator(HipModule):
             K.gemm(h, W['whh'], W['bhh'], gh, B)
             K.gru_cell_step(gi, gh, h, h, B)
         return h
+
+
+class FFN(HipModule):
+    """``FFN(sizes, dropout=0)``: the stack of linear layers the reference's callers build as ``FFN([in, ..., out])``
+    (``merge_z`` of ``/root/reference/src/prod/style_model.py:40,67``, applied to ``cat([z, morphs], dim=1)`` before the
+    decode loop).  The reference's model source is absent; this build's choice is ReLU between layers and none after
+    the last, so the one-layer form the pre-decode path uses is a plain linear map.  Inference only (``dropout`` is
+    ignored).  Input widths that are not a multiple of 4 are zero-padded (input and weight alike), which leaves every
+    output's sum of products unchanged."""
+
+    def __init__(self, sizes, dropout=0.0, device='cuda'):
+        super().__init__(device)
+        sizes = list(sizes)
+        if len(sizes) < 2:
+            raise ValueError('FFN needs at least an input and an output size')
+        self.sizes = sizes
+        for i, (n_in, n_out) in enumerate(zip(sizes[:-1], sizes[1:])):
+            self._add('layers.%d.weight' % i, (n_out, n_in), std=1.0 / math.sqrt(n_in))
+            self._add('layers.%d.bias' % i, (n_out,), fill=0.0)
+
+    def prepared(self):
+        if self._prepared is None:
+            P, layers = self._params, []
+            for i in range(len(self.sizes) - 1):
+                wt = _t(P['layers.%d.weight' % i])                 # [in, out]
+                k_pad = (wt.shape[0] + 3) // 4 * 4
+                if k_pad != wt.shape[0]:
+                    full = torch.zeros((k_pad, wt.stride(0)), dtype=torch.float32, device=wt.device)
+                    full[:wt.shape[0], :wt.shape[1]] = wt
+                    wt = full[:, :wt.shape[1]]
+                layers.append((wt, P['layers.%d.bias' % i]))
+            self._prepared = layers
+        return self._prepared
+
+    def __call__(self, x):
+        x = x.to(device=self.device, dtype=torch.float32)
+        lead, B = x.shape[:-1], x.numel() // x.shape[-1]
+        h = x.reshape(B, x.shape[-1])
+        layers = self.prepared()
+        for i, (wt, b) in enumerate(layers):
+            k_pad = wt.shape[0]
+            if h.shape[1] != k_pad or not h.is_contiguous():
+                padded = torch.zeros((B, k_pad), dtype=torch.float32, device=self.device)
+                padded[:, :h.shape[1]] = h
+                h = padded
+            n_out = wt.shape[1]
+            out = torch.empty((B, (n_out + 3) // 4 * 4), dtype=torch.float32, device=self.device)
+            K.gemm(h, wt, b, out, B, n_cols=n_out, act=0 if i == len(layers) - 1 else 1)
+            h = out[:, :n_out]
+        return h.reshape(*lead, h.shape[1]) if h.is_contiguous() else h.contiguous().reshape(*lead, h.shape[1])
