@@ -372,12 +372,19 @@ class CanonGRUDecoder:
             i += 1
         self.out = _Lin(sd, 'out')
         self.V = self.out.b.shape[0]
+        self.style_emb = _np(sd['style_embed.weight']) if 'style_embed.weight' in sd else None   # ConditionalLM
 
-    def session(self, z, rows_per_sentence=1):
+    def session(self, z, rows_per_sentence=1, style=None):
+        """``style`` (ConditionalLM): one style index for the batch or one per sentence; the style embedding is added to
+        every token embedding (one fp32 add per element)."""
         z = np.asarray(z, np.float32)
         if z.ndim == 2:
             z = z[None]
-        return _GRUSession(self, np.repeat(z, rows_per_sentence, axis=1))
+        sess = _GRUSession(self, np.repeat(z, rows_per_sentence, axis=1))
+        if self.style_emb is not None:
+            styles = np.broadcast_to(np.asarray(0 if style is None else style, np.int64).reshape(-1), (z.shape[1],))
+            sess.extra = np.repeat(self.style_emb[styles], rows_per_sentence, axis=0)
+        return sess
 
 
 def _gru_weights(sd, prefix='gru.'):
@@ -423,13 +430,19 @@ class _GRUSession:
     def __init__(self, m, h):
         self.m, self.h = m, [np.ascontiguousarray(h[i]) for i in range(h.shape[0])]
 
+    extra = None   # per-row vector added to the token embedding
+
     def reorder(self, idx):
         idx = np.asarray(idx, dtype=np.int64)
         self.h = [h[idx] for h in self.h]
+        if self.extra is not None:
+            self.extra = self.extra[idx]
 
     def step(self, tok, t):
         m = self.m
         x = embed_posadd(tok, m.emb, None, 1.0)
+        if self.extra is not None:
+            x = (x + self.extra[:x.shape[0]]).astype(np.float32)
         for i, c in enumerate(m.cells):
             gi = gemm(x, c['wih'], c['bih'])
             gh = gemm(self.h[i], c['whh'], c['bhh'])

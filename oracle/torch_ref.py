@@ -369,6 +369,26 @@ class RNNLM(nn.Module):
         return (logits, z_new) if return_z else logits
 
 
+class ConditionalLM(nn.Module):
+    """Specification of ``ConditionalLM(size, vocab)`` as called at ``/root/reference/src/prod/dialog_model.py:52,99-100``:
+    ``lm(z [2, B, size], x, style=s, return_z=True) -> (logits, z')``.  The reference's class is in the absent model-zoo
+    submodule; this build's choice: a GRU language model (two layers, as the caller's z has) whose token embeddings
+    get a learned style embedding added; ``style`` is one index for the whole batch or one per sentence."""
+
+    def __init__(self, size, vocab, n_layers=2, n_styles=2):
+        super().__init__()
+        self.embed = nn.Embedding(len(vocab), size)
+        self.style_embed = nn.Embedding(n_styles, size)
+        self.gru = nn.GRU(size, size, num_layers=n_layers, batch_first=True)
+        self.out = nn.Linear(size, len(vocab))
+
+    def forward(self, z, x, style=0, return_z=False):
+        styles = torch.as_tensor(style, dtype=torch.long, device=x.device).reshape(-1).expand(x.shape[0])
+        hid, z_new = self.gru(self.embed(x) + self.style_embed(styles).unsqueeze(1), z)
+        logits = self.out(hid)
+        return (logits, z_new) if return_z else logits
+
+
 class WeightedLMEnsemble(nn.Module):
     """Restatement of ``WeightedLMEnsemble`` at ``/root/reference/src/prod/throwaway_models.py:9-36``: every member gets
     its own state ``zs[i]``; the prediction is log(sum_i w_i * softmax(logits_i))."""

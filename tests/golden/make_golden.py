@@ -265,6 +265,31 @@ def charlm_case(InferenceState):
                                  'z0': z0.numpy(), 'z': z.numpy()}, seqs, rec, finished_lens_of(seqs, max_len))
 
 
+def conditional_case(InferenceState):
+    """A style-conditioned GRU language model under the real loop in the call pattern of
+    /root/reference/src/prod/dialog_model.py:98-120: context pass ``lm(zeros, text, style=1, return_z=True)[1]``, then the
+    stateful loop with the style in ``kwargs`` (greedy: sampling there has no fixed output)."""
+    vocab = R.synthetic_vocab(50, extra=('|',))
+    lm = R.synthetic_init(R.ConditionalLM(64, vocab), vocab.stoi['|'], 0.8, 2.0, seed=42)
+    rs = np.random.RandomState(112)
+    B, max_len = 5, 10
+    text = torch.from_numpy(rs.randint(5, 50, size=(B, 6)))
+    with torch.no_grad():
+        z = lm(torch.zeros(2, B, 64), text, style=1, return_z=True)[1]
+        rec = Recorder(lm, 4)
+        seqs = InferenceState({'model': rec, 'inputs': z, 'vocab': vocab, 'max_len': max_len, 'bos_token': '|', 'eos_token': '|',
+                               'substitute_inputs': True, 'inputs_batch_dim': 1,
+                               'kwargs': {'return_z': True, 'style': 1}}).inference()
+        other = InferenceState({'model': lm, 'inputs': z, 'vocab': vocab, 'max_len': max_len, 'bos_token': '|', 'eos_token': '|',
+                                'substitute_inputs': True, 'inputs_batch_dim': 1,
+                                'kwargs': {'return_z': True, 'style': 0}}).inference()
+    seqs = [s.tolist() for s in seqs]
+    config = dict(kind='conditional_lm', V=50, H=64, n_layers=2, weight_seed=42, eos_bias=0.8, out_scale=2.0, max_len=max_len,
+                  style=1, seqs_style0=[s.tolist() for s in other],
+                  source='specification ConditionalLM + reference src/inference.py (stateful, style in kwargs)')
+    save('conditional_lm', config, {'text': text.numpy().astype(np.int32), 'z': z.numpy()}, seqs, rec, finished_lens_of(seqs, max_len))
+
+
 def ensemble_members(V, H, n_layers, seeds, eos_bias, out_scale):
     vocab = R.synthetic_vocab(V, extra=('|',))
     return vocab, [R.synthetic_init(R.RNNLM(H, vocab, n_layers), vocab.stoi['|'], eos_bias, out_scale, seed=sd) for sd in seeds]
@@ -424,6 +449,9 @@ def postprocess_case():
 def main():
     torch.set_num_threads(4)
     InferenceState, simple_inference = import_reference()
+    if sys.argv[1:] == ['conditional']:      # only the newest case (the others are unchanged)
+        conditional_case(InferenceState)
+        return
     postprocess_case()
     m, v, e, mk = transformer_case(InferenceState, 'tfm_v64', V=64, B=6, S_max=12, max_len=16, eos_bias=1.5,
                                    out_scale=2.0, seed=101, through_encoder=False)
@@ -443,6 +471,7 @@ def main():
     gumbel_op_case()
     prefix_cases(InferenceState)
     charlm_case(InferenceState)
+    conditional_case(InferenceState)
     ensemble_case(InferenceState, 'ensemble_rnnlm', V=50, H=32, n_layers=2, B=5, max_len=12, weights=[0.25, 0.75],
                   seeds=[42, 43], eos_bias=1.0, out_scale=2.0, seed=109)
     gumbel_case(InferenceState, 'gumbel_gru', 'gru', V=40, B=5, max_len=10, temperature=0.7, eos_bias=1.0, out_scale=2.0,

@@ -68,6 +68,9 @@ def torch_model_for(cfg):
     elif kind == 'rnnlm_stateful':
         model = R.RNNLM(cfg['H'], vocab, cfg['n_layers'])
         eos = vocab.stoi['|']
+    elif kind == 'conditional_lm':
+        model = R.ConditionalLM(cfg['H'], vocab, cfg['n_layers'])
+        eos = vocab.stoi['|']
     else:
         raise ValueError(kind)
     return R.synthetic_init(model, eos, cfg['eos_bias'], cfg['out_scale'], seed=cfg['weight_seed']), vocab

@@ -414,6 +414,43 @@ def test_char_lm_from_embs_matches_reference_fixture(T):
     assert seqs_of(st.inference()) == fx['seqs']
 
 
+def test_conditional_lm_matches_reference_fixture(T):
+    """``ConditionalLM`` in the call pattern of /root/reference/src/prod/dialog_model.py:98-120: the context pass
+    ``lm(zeros, text, style=1, return_z=True)[1]`` and the stateful loop with the style in ``kwargs``, against the fixture of
+    the real loop; per-sentence styles and beam search against the canonical oracle."""
+    fx = load_fixture('conditional_lm')
+    cfg = fx['config']
+    tmodel, _ = torch_model_for(cfg)
+    vocab = T.Vocab.synthetic(cfg['V'], extra=('|',))
+    lm = T.ConditionalLM(cfg['H'], vocab)
+    lm.load_state_dict(tmodel.state_dict())
+    B = fx['z'].shape[1]
+    z = lm(torch.zeros(2, B, cfg['H']).cuda(), torch.from_numpy(fx['text']).long().cuda(), style=1, return_z=True)[1]
+    ok, err = logits_close(z.cpu().numpy(), fx['z'])
+    assert ok, err
+
+    def state(style, **extra):
+        d = {'model': lm, 'inputs': torch.from_numpy(fx['z']).cuda(), 'vocab': vocab, 'max_len': cfg['max_len'], 'bos_token': '|',
+             'eos_token': '|', 'substitute_inputs': True, 'inputs_batch_dim': 1, 'kwargs': {'return_z': True, 'style': style}}
+        d.update(extra)
+        return T.InferenceState(d)
+    st = state(cfg['style'])
+    assert seqs_of(st.inference(keep_logits=4)) == fx['seqs']
+    for i in range(sum(1 for k in fx if k.startswith('logits_s'))):
+        ok, err = logits_close(st.loop.kept[i][0].cpu().numpy(), fx['logits_s%d' % i])
+        assert ok, (i, err)
+    assert seqs_of(state(0).inference()) == cfg['seqs_style0']
+    # one style per sentence, greedy and beam 3, bit for bit against the canonical oracle
+    styles = [1, 0, 0, 1, 0]
+    dec = C.CanonGRUDecoder(tmodel)
+    want = C.greedy_decode(dec.session(fx['z'], style=styles), B, cfg['max_len'], vocab.stoi['|'], vocab.stoi['|'], 0)[0]
+    assert seqs_of(state(torch.tensor(styles)).inference()) == want
+    want_b = C.beam_decode(dec.session(fx['z'], 3, style=styles), B, 3, cfg['max_len'], vocab.stoi['|'], vocab.stoi['|'], 0.0)[0]
+    assert seqs_of(state(torch.tensor(styles), beam_size=3).inference()) == want_b
+    with pytest.raises(ValueError):
+        state(torch.tensor([0, 1])).inference()
+
+
 def test_embed_and_gru_submodules_as_the_prod_callers_use_them(T):
     """``decoder.embed(ids)`` and ``decoder.gru(embs, z.unsqueeze(0))[1].squeeze(0)`` (/root/reference/src/prod/style_model.py:64,68),
     ``lm.gru(lm.embed(text))[1]`` (/root/reference/src/prod/dialog_model.py:105-106): against the nn.Embedding / nn.GRU of the

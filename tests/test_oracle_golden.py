@@ -181,6 +181,29 @@ def ensemble_torch_model(cfg):
     return R.WeightedLMEnsemble(members, cfg['weights']).eval(), members, vocab
 
 
+def test_conditional_lm_restatements_match_reference_fixture():
+    """Style-conditioned GRU language model: the torch restatement of the loop and the canonical oracle against the
+    fixture made by the real loop (style passed through ``kwargs``), for the fixture's style and for the other one."""
+    fx = load_fixture('conditional_lm')
+    cfg = fx['config']
+    model, vocab = torch_model_for(cfg)
+    B = fx['z'].shape[1]
+    for style, want in ((cfg['style'], fx['seqs']), (0, cfg['seqs_style0'])):
+        with torch.no_grad():
+            got = R.RefInferenceState({'model': model, 'inputs': torch.from_numpy(fx['z']), 'vocab': vocab, 'max_len': cfg['max_len'],
+                                       'bos_token': '|', 'eos_token': '|', 'substitute_inputs': True, 'inputs_batch_dim': 1,
+                                       'kwargs': {'return_z': True, 'style': style}}).inference()
+        assert [s.tolist() for s in got] == want
+        sess = C.CanonGRUDecoder(model).session(fx['z'], style=style)
+        seqs, logits, rows = C.greedy_decode(sess, B, cfg['max_len'], vocab.stoi['|'], vocab.stoi['|'], KEEP)
+        assert seqs == want
+        if style == cfg['style']:
+            for i in range(sum(1 for k in fx if k.startswith('logits_s'))):
+                ok, err = logits_close(logits[i], fx['logits_s%d' % i])
+                assert ok, (i, err)
+    assert fx['seqs'] != cfg['seqs_style0']          # the style matters in this fixture
+
+
 def test_canonical_ffn_close_to_torch():
     torch.manual_seed(2)
     m = R.FFN([87, 40, 64])

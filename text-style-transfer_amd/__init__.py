@@ -10,7 +10,7 @@ from .vocab import Vocab
 from .inference import InferenceState, simple_inference
 from .transformer import HP, Transformer, TransformerDecoder
 from .encoder import TransformerEncoder
-from .rnn import CharLMFromEmbs, FFN, Generator, RNNDecoder, RNNEncoder, RNNLM, WeightedLMEnsemble
+from .rnn import CharLMFromEmbs, ConditionalLM, FFN, Generator, RNNDecoder, RNNEncoder, RNNLM, WeightedLMEnsemble
 from .lm import TransformerLM
 from .postprocess import itos_many, compute_bleu_for_sents, corpus_bleu
 

@@ -135,7 +135,10 @@ class InferenceState:
 
     def _session(self, n_positions=None):
         if hasattr(self.model, 'session') and not self.kwargs.get('force_foreign', False):
-            return self.model.session(self.inputs, self.enc_mask, self.beam_size, n_positions or self.max_len)
+            extra = {}
+            if getattr(self.model, 'session_takes_kwargs', False):   # e.g. style= of a ConditionalLM
+                extra = {k: v for k, v in self.kwargs.items() if k not in ('force_foreign', 'return_z')}
+            return self.model.session(self.inputs, self.enc_mask, self.beam_size, n_positions or self.max_len, **extra)
         kwargs = {k: v for k, v in self.kwargs.items() if k != 'force_foreign'}
         return ForeignSession(self.model, self.inputs, self.enc_mask, kwargs, self.substitute_inputs,
                               self.inputs_batch_dim, self.beam_size, len(self.vocab))

@@ -93,11 +93,12 @@ class _GRUModel(HipModule):
             x = out
         return x.view(T, B, self.H).transpose(0, 1).contiguous(), torch.stack(h_n)
 
-    def _run_prefix(self, z, x):
+    def _run_prefix(self, z, x, extra=None):
         """Teacher-forced evaluation: logits [B,T,V] and the final state [n_layers,B,H]."""
         B, T = x.shape
-        sess = GRUSession(self, z, 1)
+        sess = GRUSession(self, z, 1, extra=extra)
         rows = K.RowState(B, max(T, 1), self.device, False, 0)
+        rows.sent.copy_(torch.arange(B, dtype=torch.int32, device=self.device))
         out = torch.empty((B, T, self.V), dtype=torch.float32, device=self.device)
         x32 = x.to(device=self.device, dtype=torch.int32)
         for p in range(T):
@@ -123,15 +124,46 @@ class RNNLM(_GRUModel):
         return (logits, z_new) if return_z else logits
 
 
+class ConditionalLM(_GRUModel):
+    """``ConditionalLM(size, vocab)`` as called at ``/root/reference/src/prod/dialog_model.py:52,99-100``:
+    ``lm(z [2, B, size], x, style=s, return_z=True) -> (logits, z')``; under ``InferenceState`` the style comes in through
+    ``kwargs`` (``:119``).  The reference's model source is absent; this build's choice: a GRU language model (two
+    layers, as the caller's z has) whose token embeddings get a learned style embedding added.  ``style`` is one
+    index for the whole batch or one per sentence."""
+    session_takes_kwargs = True
+
+    def __init__(self, size, vocab, n_layers=2, n_styles=2, device='cuda'):
+        super().__init__(size, size, vocab, n_layers, device)
+        self._add('style_embed.weight', (n_styles, size), std=1.0)
+        order = ['embed.weight', 'style_embed.weight'] + [k for k in self._params if k not in ('embed.weight', 'style_embed.weight')]
+        self._params = OrderedDict((k, self._params[k]) for k in order)
+
+    def _style_rows(self, style, batch):
+        styles = torch.as_tensor(0 if style is None else style, dtype=torch.long, device=self.device).reshape(-1)
+        if styles.numel() not in (1, batch):
+            raise ValueError('style must be one index or one per sentence (%d), got %d' % (batch, styles.numel()))
+        return self._params['style_embed.weight'][styles.expand(batch)].contiguous()
+
+    def session(self, z, enc_mask=None, rows_per_sentence=1, max_len=None, style=None, **ignored):
+        batch = z.shape[1] if z.dim() == 3 else z.shape[0]
+        return GRUSession(self, z, rows_per_sentence, extra=self._style_rows(style, batch))
+
+    def __call__(self, z, x, style=None, return_z=False):
+        logits, z_new = self._run_prefix(z, x, extra=self._style_rows(style, x.shape[0]))
+        return (logits, z_new) if return_z else logits
+
+
 class GRUSession:
     """Carried hidden state [layer][row][H] (two buffers per layer: rows are re-gathered when the batch
-    is compacted or beams are reordered) and work buffers."""
+    is compacted or beams are reordered) and work buffers.  ``extra`` [B, E]: a vector per sentence that is added
+    to the embedding of each of its tokens."""
     needs_anc = False
     takes_soft = True
     incremental = True
 
-    def __init__(self, model, z, k):
+    def __init__(self, model, z, k, extra=None):
         self.m, self.V = model, model.V
+        self.extra = extra
         dev = model.device
         z = z.to(device=dev, dtype=torch.float32)
         if z.dim() == 2:
@@ -164,6 +196,8 @@ class GRUSession:
             K.embed_posadd(rows.tok, W['emb'], None, 1.0, self.x, n)
         else:   # token distributions instead of ids: expected embedding
             K.soft_embed(soft, m.soft_embedding_matrix(), 1.0, None, self.x, n)
+        if self.extra is not None:
+            K.add_rows(self.x, self.extra, rows.sent, n)
         x = self.x
         for l, c in enumerate(W['cells']):
             K.gemm(x, c['wih'], c['bih'], self.gi, n)
