@@ -29,7 +29,7 @@ extern "C" {
 #define TST_ERR_UNSUPPORTED (-3) /* shape outside what the kernel was built for */
 
 /* ABI version of this header (major * 100 + minor): 101 = 100 + tst_gemm_skinny_f32, tst_attn_cross_packed_f32,
- * tst_tfm_step_run (additions only). */
+ * tst_tfm_step_run, tst_gru_step_run, tst_gru_reorder_run, tst_select_step_run (additions only). */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
@@ -257,6 +257,53 @@ typedef struct tst_tfm_step {
  * launch and returns its code.  A caller that times the vocabulary projection calls it twice (phases 3, then 4). */
 int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const int32_t* anc, const int32_t* sent, int64_t R,
                      int64_t t, int phases, void* stream);
+
+/* One decode step of a GRU decoder / language model (embedding -> n_layers GRU cells with carried state -> linear to
+ * logits), launched from native code like tst_tfm_step_run: x = emb[tok] (+ extra[sent]); per layer gi = x Wih + bih,
+ * gh = h Whh + bhh, h = cell(gi, gh, h), x = h; logits = x Wout + bout.  Host structs, device pointers, fp32. */
+typedef struct tst_gru_layer {
+    const float* wih;  const float* bih;  int64_t ld_wih;   /* [in][3H] */
+    const float* whh;  const float* bhh;  int64_t ld_whh;   /* [H][3H] */
+    float* h;          /* [rows][H] carried state, updated in place */
+    float* h_alt;      /* [rows][H] target of tst_gru_reorder_run */
+} tst_gru_layer;
+
+typedef struct tst_gru_step {
+    int32_t n_layers, E, H, V;
+    int64_t rows;           /* capacity of the work buffers */
+    const float* emb;       /* [V][E] */
+    const float* extra;     /* [n_sent][E] added to the embedding of a sentence's rows, or NULL */
+    const float* wout;  const float* bout;  int64_t ld_wout;
+    float *x, *gi, *gh;     /* [rows][E], [rows][3H], [rows][3H] */
+    float* logits;  int64_t ld_logits;
+    const tst_gru_layer* layers;   /* host array of n_layers */
+} tst_gru_step;
+
+/* phases as for tst_tfm_step_run (TST_STEP_EMBED | TST_STEP_LAYERS | TST_STEP_VOCAB). */
+int tst_gru_step_run(const tst_gru_step* m, const int32_t* tok, const int32_t* sent, int64_t R, int phases, void* stream);
+/* h_alt[r] = h[row_parent[r]] for every layer (rows re-gathered after compaction / a beam reorder); the caller then
+ * swaps h and h_alt in its struct. */
+int tst_gru_reorder_run(const tst_gru_step* m, const int32_t* row_parent, int64_t R, void* stream);
+
+/* The tail of a decode step in one call: token selection on the logits, then retirement and compaction.
+ *   k == 1: tst_argmax_rows (sample == 0) or tst_sample_rows (sample != 0), tst_greedy_select
+ *   k  > 1: tst_logsoftmax_topk, tst_beam_merge
+ *   then tst_retire_compact.  Arguments as for those entry points; the struct holds what stays the same over the steps
+ *   of one decode call. */
+typedef struct tst_select_step {
+    int32_t k, eos, V, bf16_logits;
+    const void* logits;  int64_t ld_logits;
+    int32_t* am;                                   /* [rows] selected token (k == 1) */
+    float* top_val;  int32_t* top_idx;  float* lse;   /* [rows][k], [rows][k], [rows] (k > 1) */
+    int32_t* sel_parent;  int32_t* sel_tok;  float* sel_score;  int32_t* sel_fin;  int32_t* sel_nemit;
+    const float* lp;  int64_t T;  int32_t top_ends;  int32_t sample;
+    float temperature;  uint32_t seed;
+    int32_t* out_tok;  int32_t* out_len;  float* out_score;  int32_t* scratch_alive_pos;  int32_t* row_parent;
+    int32_t* n_alive;
+} tst_select_step;
+
+int tst_select_step_run(const tst_select_step* s, const tst_rows* cur, const tst_rows* nxt, int64_t n_sent, int64_t k_in,
+                        int64_t step, uint32_t sample_step, int last_step, void* stream);
 
 #ifdef __cplusplus
 }

@@ -54,6 +54,19 @@ def test_argument_errors_are_reported_not_crashed():
         _lib.call('tst_tfm_step_run', plan, None, None, None, 2, 4, 7, None)
     with pytest.raises(_lib.TstError, match='bad phases'):
         _lib.call('tst_tfm_step_run', plan, None, None, None, 2, 0, 8, None)
+    with pytest.raises(_lib.TstError, match='null plan'):
+        _lib.call('tst_gru_step_run', None, None, None, 1, 7, None)
+    gl = (_lib.TstGruLayer * 1)()
+    gplan = _lib.TstGruStep(n_layers=1, E=8, H=8, V=10, rows=2, layers=gl)
+    with pytest.raises(_lib.TstError, match='buffers hold 2'):
+        _lib.call('tst_gru_step_run', gplan, None, None, 3, 7, None)
+    with pytest.raises(_lib.TstError, match='null pointer'):
+        _lib.call('tst_gru_reorder_run', gplan, None, 1, None)
+    rows = _lib.TstRows()
+    with pytest.raises(_lib.TstError, match='bad sizes'):
+        _lib.call('tst_select_step_run', _lib.TstSelectStep(k=9), rows, rows, 1, 1, 0, 0, 0, None)
+    with pytest.raises(_lib.TstError, match='bad sizes'):
+        _lib.call('tst_select_step_run', _lib.TstSelectStep(k=4), rows, rows, 1, 2, 0, 0, 0, None)
 
 
 def test_no_product_module_touches_the_oracle():

@@ -47,6 +47,31 @@ class TstTfmStep(ctypes.Structure):
                 ('layers', ctypes.POINTER(TstTfmLayer))]
 
 
+class TstGruLayer(ctypes.Structure):
+    """``tst_gru_layer`` of include/tst_hip.h"""
+    _fields_ = [('wih', c_vp), ('bih', c_vp), ('ld_wih', c_i64), ('whh', c_vp), ('bhh', c_vp), ('ld_whh', c_i64),
+                ('h', c_vp), ('h_alt', c_vp)]
+
+
+class TstGruStep(ctypes.Structure):
+    """``tst_gru_step`` of include/tst_hip.h"""
+    _fields_ = [('n_layers', c_i32), ('E', c_i32), ('H', c_i32), ('V', c_i32), ('rows', c_i64),
+                ('emb', c_vp), ('extra', c_vp), ('wout', c_vp), ('bout', c_vp), ('ld_wout', c_i64),
+                ('x', c_vp), ('gi', c_vp), ('gh', c_vp), ('logits', c_vp), ('ld_logits', c_i64),
+                ('layers', ctypes.POINTER(TstGruLayer))]
+
+
+class TstSelectStep(ctypes.Structure):
+    """``tst_select_step`` of include/tst_hip.h"""
+    _fields_ = [('k', c_i32), ('eos', c_i32), ('V', c_i32), ('bf16_logits', c_i32), ('logits', c_vp), ('ld_logits', c_i64),
+                ('am', c_vp), ('top_val', c_vp), ('top_idx', c_vp), ('lse', c_vp),
+                ('sel_parent', c_vp), ('sel_tok', c_vp), ('sel_score', c_vp), ('sel_fin', c_vp), ('sel_nemit', c_vp),
+                ('lp', c_vp), ('T', c_i64), ('top_ends', c_i32), ('sample', c_i32), ('temperature', c_f32),
+                ('seed', ctypes.c_uint32),
+                ('out_tok', c_vp), ('out_len', c_vp), ('out_score', c_vp), ('scratch_alive_pos', c_vp), ('row_parent', c_vp),
+                ('n_alive', c_vp)]
+
+
 STEP_EMBED, STEP_LAYERS, STEP_VOCAB = 1, 2, 4
 
 _PROTOS = {
@@ -80,6 +105,10 @@ _PROTOS = {
                         c_vp], c_int),
     'tst_greedy_select': ([c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(TstRows), c_vp], c_int),
     'tst_tfm_step_run': ([ctypes.POINTER(TstTfmStep), c_vp, c_vp, c_vp, c_i64, c_i64, c_int, c_vp], c_int),
+    'tst_gru_step_run': ([ctypes.POINTER(TstGruStep), c_vp, c_vp, c_i64, c_int, c_vp], c_int),
+    'tst_gru_reorder_run': ([ctypes.POINTER(TstGruStep), c_vp, c_i64, c_vp], c_int),
+    'tst_select_step_run': ([ctypes.POINTER(TstSelectStep), ctypes.POINTER(TstRows), ctypes.POINTER(TstRows), c_i64, c_i64, c_i64,
+                             ctypes.c_uint32, c_int, c_vp], c_int),
     'tst_retire_compact': ([ctypes.POINTER(TstRows), ctypes.POINTER(TstRows), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
                             c_i64, c_i64, c_i64, c_i32, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_int),
 }

@@ -94,3 +94,79 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
     }
     return TST_OK;
 }
+
+extern "C" int tst_gru_step_run(const tst_gru_step* m, const int32_t* tok, const int32_t* sent, int64_t R, int phases, void* stream) {
+    TST_REQUIRE(m != nullptr && m->layers != nullptr, TST_ERR_ARG, "tst_gru_step_run: null plan");
+    TST_REQUIRE(m->n_layers >= 1 && m->E > 0 && m->H > 0 && m->V > 0, TST_ERR_ARG, "tst_gru_step_run: bad sizes");
+    TST_REQUIRE(R >= 0 && R <= m->rows, TST_ERR_ARG, "tst_gru_step_run: %lld rows, buffers hold %lld", (long long)R, (long long)m->rows);
+    TST_REQUIRE((phases & ~7) == 0 && phases != 0, TST_ERR_ARG, "tst_gru_step_run: bad phases %d", phases);
+    TST_REQUIRE(m->x && m->gi && m->gh && m->logits, TST_ERR_ARG, "tst_gru_step_run: null work buffer");
+    if (R == 0) return TST_OK;
+    if (phases & TST_STEP_EMBED) {
+        TST_REQUIRE(tok && m->emb, TST_ERR_ARG, "tst_gru_step_run: null embedding input");
+        TST_TRY(tst_embed_posadd_f32(tok, m->emb, nullptr, nullptr, 1.0f, m->x, R, m->E, m->V, stream));
+    }
+    const tst_gru_layer& top = m->layers[m->n_layers - 1];
+    if (phases & TST_STEP_LAYERS) {
+        if (m->extra != nullptr) {
+            TST_REQUIRE(sent != nullptr, TST_ERR_ARG, "tst_gru_step_run: extra without sent");
+            TST_TRY(tst_add_rows_f32(m->x, m->extra, sent, R, m->E, stream));
+        }
+        const float* x = m->x;
+        int64_t in = m->E;
+        for (int l = 0; l < m->n_layers; ++l) {
+            const tst_gru_layer& L = m->layers[l];
+            TST_REQUIRE(L.wih && L.whh && L.h, TST_ERR_ARG, "tst_gru_step_run: layer %d incomplete", l);
+            TST_TRY(tst_gemm_mfma_f32(x, in, L.wih, L.ld_wih, L.bih, nullptr, 0, m->gi, 3 * m->H, R, 3 * m->H, in, 0, stream));
+            TST_TRY(tst_gemm_mfma_f32(L.h, m->H, L.whh, L.ld_whh, L.bhh, nullptr, 0, m->gh, 3 * m->H, R, 3 * m->H, m->H, 0, stream));
+            TST_TRY(tst_gru_cell_step_f32(m->gi, m->gh, L.h, L.h, R, m->H, stream));
+            x = L.h;
+            in = m->H;
+        }
+    }
+    if (phases & TST_STEP_VOCAB) {
+        TST_REQUIRE(m->wout != nullptr, TST_ERR_ARG, "tst_gru_step_run: null output projection");
+        TST_TRY(tst_gemm_mfma_f32(top.h, m->H, m->wout, m->ld_wout, m->bout, nullptr, 0, m->logits, m->ld_logits, R, m->V, m->H, 0,
+                                  stream));
+    }
+    return TST_OK;
+}
+
+extern "C" int tst_gru_reorder_run(const tst_gru_step* m, const int32_t* row_parent, int64_t R, void* stream) {
+    TST_REQUIRE(m != nullptr && m->layers != nullptr && row_parent != nullptr, TST_ERR_ARG, "tst_gru_reorder_run: null pointer");
+    TST_REQUIRE(R >= 0 && R <= m->rows, TST_ERR_ARG, "tst_gru_reorder_run: %lld rows, buffers hold %lld", (long long)R,
+                (long long)m->rows);
+    for (int l = 0; l < m->n_layers; ++l) {
+        TST_REQUIRE(m->layers[l].h && m->layers[l].h_alt, TST_ERR_ARG, "tst_gru_reorder_run: layer %d incomplete", l);
+        TST_TRY(tst_gather_rows_f32(m->layers[l].h, row_parent, m->layers[l].h_alt, R, m->H, stream));
+    }
+    return TST_OK;
+}
+
+extern "C" int tst_select_step_run(const tst_select_step* s, const tst_rows* cur, const tst_rows* nxt, int64_t n_sent, int64_t k_in,
+                                   int64_t step, uint32_t sample_step, int last_step, void* stream) {
+    TST_REQUIRE(s != nullptr && cur != nullptr && nxt != nullptr, TST_ERR_ARG, "tst_select_step_run: null pointer");
+    TST_REQUIRE(s->k >= 1 && s->k <= 8 && (k_in == 1 || k_in == s->k) && n_sent >= 0, TST_ERR_ARG, "tst_select_step_run: bad sizes");
+    const int64_t R = n_sent * k_in;
+    if (s->k == 1) {
+        if (s->sample) {
+            TST_TRY(s->bf16_logits ? tst_sample_rows_bf16(s->logits, s->ld_logits, R, s->V, s->temperature, s->seed, sample_step,
+                                                          cur->sent, s->am, stream)
+                                   : tst_sample_rows_f32((const float*)s->logits, s->ld_logits, R, s->V, s->temperature, s->seed,
+                                                         sample_step, cur->sent, s->am, stream));
+        } else {
+            TST_TRY(s->bf16_logits ? tst_argmax_rows_bf16(s->logits, s->ld_logits, R, s->V, s->am, stream)
+                                   : tst_argmax_rows_f32((const float*)s->logits, s->ld_logits, R, s->V, s->am, stream));
+        }
+        TST_TRY(tst_greedy_select(s->am, R, s->eos, s->sel_parent, s->sel_tok, s->sel_score, s->sel_fin, s->sel_nemit, cur, stream));
+    } else {
+        TST_TRY(s->bf16_logits ? tst_logsoftmax_topk_bf16(s->logits, s->ld_logits, R, s->V, s->k, s->top_val, s->top_idx, s->lse, stream)
+                               : tst_logsoftmax_topk_f32((const float*)s->logits, s->ld_logits, R, s->V, s->k, s->top_val, s->top_idx,
+                                                         s->lse, stream));
+        TST_TRY(tst_beam_merge(cur, s->top_val, s->top_idx, s->lse, n_sent, s->k, k_in, s->eos, s->sel_parent, s->sel_tok, s->sel_score,
+                               s->sel_fin, s->sel_nemit, stream));
+    }
+    return tst_retire_compact(cur, nxt, s->sel_parent, s->sel_tok, s->sel_score, s->sel_fin, s->sel_nemit, s->lp, n_sent, s->k, step, s->T,
+                              s->eos, last_step, s->top_ends, s->out_tok, s->out_len, s->out_score, s->scratch_alive_pos, s->row_parent,
+                              s->n_alive, stream);
+}

@@ -27,6 +27,12 @@ def length_penalty_table(max_len, alpha):
     return torch.tensor([((5.0 + n) / 6.0) ** alpha for n in range(max_len + 2)], dtype=torch.float32)
 
 
+def _check_logits(logits, n_rows, V):
+    if not (logits.is_cuda and logits.dim() == 2 and logits.stride(1) == 1 and logits.shape[0] >= n_rows and logits.shape[1] >= V):
+        raise ValueError('a model step must return logits [>= %d rows, >= %d columns] on the GPU with unit inner stride, got %s'
+                         % (n_rows, V, tuple(logits.shape)))
+
+
 class DecodeLoop:
     def __init__(self, session, n_sent, beam, max_len, bos, eos, pad, alpha=0.0, device=None, sample=None, gumbel=None,
                  prefix=None):
@@ -75,10 +81,12 @@ class DecodeLoop:
         self.row_parent = torch.zeros(R, **i32)
         self.n_alive = torch.zeros(1, **i32)
         self.am = torch.zeros(R, **i32)
+        self.top_val = self.top_idx = self.lse = None
         if beam > 1:
             self.top_val = torch.zeros((R, beam), dtype=torch.float32, device=dev)
             self.top_idx = torch.zeros((R, beam), **i32)
             self.lse = torch.zeros(R, dtype=torch.float32, device=dev)
+        self.tail = None   # kernels.SelectPlan, made at the first step (it needs the session's logits buffer)
         # Soft decoding (``gumbel=True`` of /root/reference/src/inference.py:104-105,136-138): the next input of a row
         # is the distribution softmax((softmax(logits) + G) / temperature) instead of a token id; the token that
         # decides about EOS is still the arg-max / sample of the raw logits.  gumbel = (temperature, prefix [B, V],
@@ -123,26 +131,37 @@ class DecodeLoop:
                 logits = s.step(self.cur, R, t, soft=self.dist_in)
             if t < keep_logits:
                 self.kept.append((logits[:R, :s.V].clone(), self.cur.sent[:R].clone(), self.cur.fin[:R].clone()))
-            if k == 1:
-                if self.sample is None:
-                    K.argmax_rows(logits, R, s.V, self.am)
-                else:
-                    K.sample_rows(logits, R, s.V, self.sample[0], self.sample[1], t, self.cur.sent, self.am)
-                K.greedy_select(self.am, R, self.eos, self.sel, self.cur)
-                if self.gumbel is not None:
-                    u = self.gumbel[2](R, s.V)
-                    K.gumbel_softmax(logits, R, s.V, u, self.gumbel[0], self.dist_out)
-                    self.dist_seq[:, t + 1].index_copy_(0, self.cur.sent[:R].long(), self.dist_out[:R, :s.V])
+            if self.gumbel is None and self.select_log is None:
+                # selection, retirement and compaction: one native call
+                if self.tail is None:
+                    _check_logits(logits, R, s.V)
+                    self.tail = K.SelectPlan(k=k, eos=self.eos, V=s.V, logits=logits, am=self.am, top_val=self.top_val,
+                                             top_idx=self.top_idx, lse=self.lse, sel=self.sel, lp=self.lp, T=Ttot,
+                                             top_ends=self.top_ends, sample=self.sample, out_tok=self.out_tok, out_len=self.out_len,
+                                             out_score=self.out_score, scratch=self.scratch, row_parent=self.row_parent,
+                                             n_alive=self.n_alive)
+                elif logits.data_ptr() != self.tail.logits_ptr:
+                    _check_logits(logits, R, s.V)
+                    self.tail.set_logits(logits)
+                self.tail.run(self.cur, self.nxt, n_sent, k_in, pos0 + t, t, t == T - 1)
             else:
-                if self.select_log is None:
-                    K.logsoftmax_topk(logits, R, s.V, k, self.top_val, self.top_idx, self.lse)
-                else:  # measurement aid: HIP events on the launch stream around the selection pass
+                if k == 1:
+                    if self.sample is None:
+                        K.argmax_rows(logits, R, s.V, self.am)
+                    else:
+                        K.sample_rows(logits, R, s.V, self.sample[0], self.sample[1], t, self.cur.sent, self.am)
+                    K.greedy_select(self.am, R, self.eos, self.sel, self.cur)
+                    if self.gumbel is not None:
+                        u = self.gumbel[2](R, s.V)
+                        K.gumbel_softmax(logits, R, s.V, u, self.gumbel[0], self.dist_out)
+                        self.dist_seq[:, t + 1].index_copy_(0, self.cur.sent[:R].long(), self.dist_out[:R, :s.V])
+                else:   # measurement aid: HIP events on the launch stream around the selection pass
                     self.select_log.begin()
                     K.logsoftmax_topk(logits, R, s.V, k, self.top_val, self.top_idx, self.lse)
                     self.select_log.end(float(R) * s.V * logits.element_size())
-                K.beam_merge(self.cur, self.top_val, self.top_idx, self.lse, n_sent, k, k_in, self.eos, self.sel)
-            K.retire_compact(self.cur, self.nxt, self.sel, self.lp, n_sent, k, pos0 + t, Ttot, self.eos, t == T - 1, self.top_ends,
-                             self.out_tok, self.out_len, self.out_score, self.scratch, self.row_parent, self.n_alive)
+                    K.beam_merge(self.cur, self.top_val, self.top_idx, self.lse, n_sent, k, k_in, self.eos, self.sel)
+                K.retire_compact(self.cur, self.nxt, self.sel, self.lp, n_sent, k, pos0 + t, Ttot, self.eos, t == T - 1, self.top_ends,
+                                 self.out_tok, self.out_len, self.out_score, self.scratch, self.row_parent, self.n_alive)
             self.cur, self.nxt = self.nxt, self.cur
             self.steps_done += 1
             self.rows_stepped += R

@@ -10,7 +10,14 @@ from . import _lib
 from ._lib import call, STEP_EMBED, STEP_LAYERS, STEP_VOCAB  # noqa: F401
 
 
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+
+
 def _stream():
+    """hipStream_t of torch's current stream on the current device (the raw-handle query is ~10x cheaper than building a
+    torch.cuda.Stream object, and this runs once per native call)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -203,6 +210,60 @@ class StepPlan:
         call('tst_tfm_step_run', self.c, _p(rows.tok), _p(rows.anc), _p(rows.sent), n_rows, t, phases, _stream())
 
 
+class GruPlan:
+    """Host-side ``tst_gru_step`` of one GRU decode session (see ``StepPlan``).  ``cells`` is a list of dicts with
+    ``wih, bih, whh, bhh``; ``h`` / ``h_alt`` are the session's lists of state buffers, which ``swap()`` exchanges
+    after a reorder."""
+
+    def __init__(self, *, E, H, V, rows, emb, extra, cells, h, h_alt, wout, bout, x, gi, gh, logits):
+        self._keep = [emb, extra, cells, h, h_alt, wout, bout, x, gi, gh, logits]
+        n = len(cells)
+        self._layers = (_lib.TstGruLayer * n)()
+        for dst, c, a, b in zip(self._layers, cells, h, h_alt):
+            dst.wih, dst.bih, dst.ld_wih = _p(c['wih']), _p(c['bih']), c['wih'].stride(0)
+            dst.whh, dst.bhh, dst.ld_whh = _p(c['whh']), _p(c['bhh']), c['whh'].stride(0)
+            dst.h, dst.h_alt = _p(a), _p(b)
+        self.c = _lib.TstGruStep(n_layers=n, E=E, H=H, V=V, rows=rows, emb=_p(emb), extra=_p(extra), wout=_p(wout), bout=_p(bout),
+                                 ld_wout=wout.stride(0), x=_p(x), gi=_p(gi), gh=_p(gh), logits=_p(logits),
+                                 ld_logits=logits.stride(0), layers=self._layers)
+
+    def run(self, rows, n_rows, phases):
+        call('tst_gru_step_run', self.c, _p(rows.tok), _p(rows.sent), n_rows, phases, _stream())
+
+    def reorder(self, row_parent, n_rows):
+        call('tst_gru_reorder_run', self.c, _p(row_parent), n_rows, _stream())
+        for L in self._layers:
+            L.h, L.h_alt = L.h_alt, L.h
+
+
+class SelectPlan:
+    """Host-side ``tst_select_step``: selection + retirement + compaction of one decode step as ONE native call."""
+
+    def __init__(self, *, k, eos, V, logits, am, top_val, top_idx, lse, sel, lp, T, top_ends, sample, out_tok, out_len, out_score,
+                 scratch, row_parent, n_alive):
+        self._keep = [logits, am, top_val, top_idx, lse, sel, lp, out_tok, out_len, out_score, scratch, row_parent, n_alive]
+        _logits_suffix(logits)   # fp32 or bf16, unit inner stride
+        sp = sel.ptrs()
+        self.c = _lib.TstSelectStep(
+            k=k, eos=eos, V=V, bf16_logits=int(logits.dtype == torch.bfloat16), logits=_p(logits), ld_logits=logits.stride(0),
+            am=_p(am), top_val=_p(top_val), top_idx=_p(top_idx), lse=_p(lse), sel_parent=sp[0], sel_tok=sp[1], sel_score=sp[2],
+            sel_fin=sp[3], sel_nemit=sp[4], lp=_p(lp), T=T, top_ends=int(top_ends), sample=int(sample is not None),
+            temperature=float(sample[0]) if sample is not None else 1.0, seed=(int(sample[1]) & 0xffffffff) if sample is not None else 0,
+            out_tok=_p(out_tok), out_len=_p(out_len), out_score=_p(out_score), scratch_alive_pos=_p(scratch),
+            row_parent=_p(row_parent), n_alive=_p(n_alive))
+        self.logits_ptr = _p(logits)
+
+    def set_logits(self, logits):
+        """A model that returns a new logits tensor every step (any foreign callable)."""
+        _logits_suffix(logits)
+        self._keep[0] = logits
+        self.c.logits, self.c.ld_logits, self.c.bf16_logits = _p(logits), logits.stride(0), int(logits.dtype == torch.bfloat16)
+        self.logits_ptr = _p(logits)
+
+    def run(self, cur, nxt, n_sent, k_in, step, sample_step, last_step):
+        call('tst_select_step_run', self.c, cur.struct(), nxt.struct(), n_sent, k_in, step, sample_step, int(last_step), _stream())
+
+
 class RowState:
     """Per-row decode state on the device (``tst_rows``): token history, ancestor table, scores, flags."""
 
@@ -216,9 +277,13 @@ class RowState:
         self.fin = torch.zeros(rows, **i32)
         self.nemit = torch.zeros(rows, **i32)
 
+        self._struct = None
+
     def struct(self):
-        return _lib.TstRows(_p(self.hist), _p(self.anc), _p(self.sent), _p(self.tok), _p(self.score), _p(self.fin),
-                            _p(self.nemit))
+        if self._struct is None:   # the buffers live as long as this object
+            self._struct = _lib.TstRows(_p(self.hist), _p(self.anc), _p(self.sent), _p(self.tok), _p(self.score), _p(self.fin),
+                                        _p(self.nemit))
+        return self._struct
 
 
 class Selection:

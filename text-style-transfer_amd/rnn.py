@@ -182,29 +182,29 @@ class GRUSession:
         self.gi = torch.empty((R, 3 * model.H), **f32)
         self.gh = torch.empty((R, 3 * model.H), **f32)
         self.logits = torch.empty((R, (model.V + 3) // 4 * 4), **f32)
+        self.plan = None
+
+    def _plan(self):
+        if self.plan is None:
+            m, W = self.m, self.m.prepared()
+            self.plan = K.GruPlan(E=m.E, H=m.H, V=m.V, rows=self.R, emb=W['emb'], extra=self.extra, cells=W['cells'], h=self.h,
+                                  h_alt=self.h_alt, wout=W['wout'], bout=W['bout'], x=self.x, gi=self.gi, gh=self.gh, logits=self.logits)
+        return self.plan
 
     def reorder(self, row_parent, n_rows, identity):
         if identity:
             return
-        for l in range(len(self.h)):
-            K.gather_rows(self.h[l], row_parent, self.h_alt[l], n_rows)
-            self.h[l], self.h_alt[l] = self.h_alt[l], self.h[l]
+        self._plan().reorder(row_parent, n_rows)      # one native call gathers every layer's state
+        self.h, self.h_alt = self.h_alt, self.h
 
     def step(self, rows, n, t, soft=None):
-        m, W = self.m, self.m.prepared()
+        """One native call issues the launches of the step (embedding, cells, output projection)."""
+        phases = K.STEP_LAYERS | K.STEP_VOCAB
         if soft is None:
-            K.embed_posadd(rows.tok, W['emb'], None, 1.0, self.x, n)
+            phases |= K.STEP_EMBED
         else:   # token distributions instead of ids: expected embedding
-            K.soft_embed(soft, m.soft_embedding_matrix(), 1.0, None, self.x, n)
-        if self.extra is not None:
-            K.add_rows(self.x, self.extra, rows.sent, n)
-        x = self.x
-        for l, c in enumerate(W['cells']):
-            K.gemm(x, c['wih'], c['bih'], self.gi, n)
-            K.gemm(self.h[l], c['whh'], c['bhh'], self.gh, n)
-            K.gru_cell_step(self.gi, self.gh, self.h[l], self.h[l], n)
-            x = self.h[l]
-        K.gemm(x, W['wout'], W['bout'], self.logits, n, n_cols=self.V)
+            K.soft_embed(soft, self.m.soft_embedding_matrix(), 1.0, None, self.x, n)
+        self._plan().run(rows, n, phases)
         return self.logits
 
 
