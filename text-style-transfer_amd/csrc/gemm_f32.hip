@@ -415,7 +415,7 @@ extern "C" int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, i
     if (M == 0) return TST_OK;
     TST_REQUIRE(((M + 63) / 64) * ((N + 63) / 64) < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_f32: grid too large");
     // Few output elements: one wave per strip (measured crossovers on the decode shapes, in 16 x 16 tiles of C).
-    // Otherwise 128 x 128 tiles unless they would give fewer than two workgroups per CU (256 CUs): then 64 x 64.
+    // Otherwise 128 x 128 tiles unless they would give fewer than 2.5 workgroups per CU (256 CUs; measured crossover): then 64 x 64.
     const int64_t tiles16 = ((M + 15) / 16) * ((N + 15) / 16);
     const int64_t big_tiles = ((M + 127) / 128) * ((N + 127) / 128);
     if (tiles16 <= 768)
@@ -426,7 +426,7 @@ extern "C" int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, i
         launch_skinny<4>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
     else if (big_tiles >= 4096 && N >= 2048)
         launch_gemm<2, 4>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
-    else if (big_tiles >= 512)
+    else if (big_tiles >= 640)
         launch_gemm<2, 2>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
     else
         launch_gemm<1, 1>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
