@@ -29,7 +29,8 @@ extern "C" {
 #define TST_ERR_UNSUPPORTED (-3) /* shape outside what the kernel was built for */
 
 /* ABI version of this header (major * 100 + minor): 101 = 100 + tst_gemm_skinny_f32, tst_attn_cross_packed_f32,
- * tst_tfm_step_run, tst_gru_step_run, tst_gru_reorder_run, tst_select_step_run (additions only). */
+ * tst_tfm_step_run, tst_gru_step_run, tst_gru_reorder_run, tst_select_step_run,
+ * tst_attn_cross_group_f32 (additions only). */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
@@ -103,6 +104,14 @@ int tst_attn_cross_step_f32(const float* q, const float* kv, const uint8_t* mask
  * (/root/reference/src/trainers/transformer_mt_trainer.py:91), which then computes nothing for padding. */
 int tst_attn_cross_packed_f32(const float* q, const float* kv, const uint8_t* mask, const int32_t* sent, const int32_t* kvrow,
                               int64_t S, float* out, int64_t R, int64_t d, int64_t heads, void* stream);
+
+/* Cross-attention step for beam search: rows g*group .. g*group + group - 1 are the hypotheses of one sentence and share
+ * its keys and values, which are then loaded once per group instead of once per row (group = 2, 4 or 8; any other value,
+ * R % group != 0 or an unsupported head size run the row-per-wave kernel).  A group whose rows do not name the same
+ * sentence is computed row by row, so the grouping is a hint, never a requirement.  kvrow NULL: kv is
+ * [n_sent][S][2*d]; else kv is packed as for tst_attn_cross_packed_f32.  Results are identical to those entry points. */
+int tst_attn_cross_group_f32(const float* q, const float* kv, const uint8_t* mask, const int32_t* sent, const int32_t* kvrow,
+                             int64_t S, float* out, int64_t R, int64_t d, int64_t heads, int64_t group, void* stream);
 
 /* The two attention steps with bf16 cache / q / k|v / output (same layouts, 2-byte elements); scores,
  * softmax and the value sum are computed in fp32 in the same order as the fp32 kernels. */
@@ -230,6 +239,9 @@ typedef struct tst_tfm_layer {
 
 typedef struct tst_tfm_step {
     int32_t n_layers, d, heads, d_ff, V, bf16;
+    int32_t group;          /* adjacent rows per sentence at THIS step (hint for tst_attn_cross_group_f32), or 0 / 1;
+                               the caller may change it between calls */
+    int32_t reserved;
     int64_t n_pos, slab_rows, S, anc_ld;
     const float* emb;       /* [V][d] */
     const float* pe;        /* [n_pos][d] positional rows */

@@ -137,6 +137,41 @@ def test_attn_cross_step_bit_exact(K, d, heads, S, masked):
     assert np.array_equal(out.cpu().numpy(), want)
 
 
+@pytest.mark.parametrize('group', [2, 4, 8, 3])
+@pytest.mark.parametrize('d,heads,S', [(256, 2, 42), (128, 4, 17), (64, 1, 70), (512, 8, 9)])
+def test_attn_cross_group_bit_exact(K, d, heads, S, group):
+    """Beams of a sentence as adjacent rows: keys / values loaded once per group.  Same bits as the oracle for groups that
+    share a sentence, for groups that do not (computed row by row), with a packed k|v, and for the sizes the grouped
+    kernel is not built for (group 3, 64-element heads: the row-per-wave kernel runs)."""
+    r = rs(d + S + group)
+    B = 9
+    n_groups = 11
+    R = n_groups * group
+    q = r.standard_normal((R, d)).astype(np.float32)
+    kv = r.standard_normal((B, S, 2 * d)).astype(np.float32)
+    sent = np.repeat(r.randint(0, B, size=n_groups), group).astype(np.int32)
+    sent[group:2 * group] = r.randint(0, B, size=group)          # one group of unrelated rows
+    sent[-1] = (sent[-1] + 1) % B                                # and one with a single stray row
+    lens = r.randint(2, S + 1, size=B)                            # every sentence keeps a position after the hole below
+    mask = (np.arange(S)[None] < lens[:, None]).astype(np.uint8)
+    mask[3, 0] = 0                                                # a hole, not only trailing padding
+    want = C.attention(q, kv[:, :, :d], kv[:, :, d:], sent, mask, S, heads)
+    out = torch.full((R, d), 7.0, dtype=torch.float32, device='cuda')
+    K.attn_cross_step(dev(q), dev(kv), dev(mask), dev(sent), out, R, d, heads, group=group)
+    assert np.array_equal(out.cpu().numpy(), want)
+    # packed k|v: only the unmasked positions exist
+    live = mask.reshape(-1) != 0
+    kvrow = (np.cumsum(live) - 1).astype(np.int32).reshape(B, S)
+    packed = kv.reshape(B * S, 2 * d)[live]
+    out2 = torch.full((R, d), 7.0, dtype=torch.float32, device='cuda')
+    K.attn_cross_step(dev(q), dev(packed), dev(mask), dev(sent), out2, R, d, heads, kvrow=dev(kvrow), group=group)
+    assert np.array_equal(out2.cpu().numpy(), want)
+    # a row count that is no multiple of the group
+    out3 = torch.full((R, d), 7.0, dtype=torch.float32, device='cuda')
+    K.attn_cross_step(dev(q), dev(kv), dev(mask), dev(sent), out3, R - 1, d, heads, group=group)
+    assert np.array_equal(out3.cpu().numpy()[:R - 1], want[:R - 1]) and (out3.cpu().numpy()[R - 1] == 7.0).all()
+
+
 def test_gru_cell_bit_exact(K):
     r = rs(11)
     R, H = 19, 64

@@ -39,7 +39,7 @@ class TstTfmLayer(ctypes.Structure):
 class TstTfmStep(ctypes.Structure):
     """``tst_tfm_step`` of include/tst_hip.h"""
     _fields_ = [('n_layers', c_i32), ('d', c_i32), ('heads', c_i32), ('d_ff', c_i32), ('V', c_i32), ('bf16', c_i32),
-                ('n_pos', c_i64), ('slab_rows', c_i64), ('S', c_i64), ('anc_ld', c_i64),
+                ('group', c_i32), ('reserved', c_i32), ('n_pos', c_i64), ('slab_rows', c_i64), ('S', c_i64), ('anc_ld', c_i64),
                 ('emb', c_vp), ('pe', c_vp), ('scale', c_f32), ('eps', c_f32),
                 ('z', c_vp), ('mask', c_vp), ('kvrow', c_vp), ('ln_g', c_vp), ('ln_b', c_vp),
                 ('wout', c_vp), ('bout', c_vp), ('ld_wout', c_i64),
@@ -85,6 +85,7 @@ _PROTOS = {
     'tst_attn_self_step_f32': ([c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_attn_cross_step_f32': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_attn_cross_packed_f32': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
+    'tst_attn_cross_group_f32': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_gru_cell_step_f32': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_gather_rows_f32': ([c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_argmax_rows_f32': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_vp], c_int),

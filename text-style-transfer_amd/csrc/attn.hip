@@ -348,6 +348,200 @@ int launch_attn(const T* base, int64_t slab_stride, const int32_t* anc, int64_t 
     return tst_after_launch(name);
 }
 
+// Cross-attention for beam search: the KB hypotheses of one sentence are adjacent rows and attend to the SAME keys and
+// values, so one wave serves (KB rows, head): every key / value element is loaded once and used for KB queries.
+// Per row the arithmetic and its order are those of attn_step_kernel (scores: 16 partials + butterfly; softmax: one
+// score per lane and 64-position block; value sum over the listed positions in ascending order), so results are
+// bit-identical.  A group whose rows do not all name the same sentence (the first step of a decode call runs one
+// row per sentence) is computed row by row.  No workgroup barrier: all LDS state is private to the wave.
+template <typename T, int KB, int NCH, int VEC>
+__device__ __forceinline__ void attend_rows(const T* __restrict__ base, const int32_t* __restrict__ kvrow, const T* __restrict__ qbuf,
+                                            const uint8_t* __restrict__ mask, int64_t ent, int n, T* __restrict__ out, int64_t r0,
+                                            int d, int h, int dh, float scale, float (*sc)[MAXP], int* slot, int* kvr, int lane) {
+    int nl = 0;
+    for (int p0 = 0; p0 < n; p0 += 64) {
+        const int p = p0 + lane;
+        const bool live = p < n && (mask == nullptr || mask[ent * n + p] != 0);
+        const unsigned long long bal = __ballot(live);
+        if (live) {
+            const int at = nl + __popcll(bal & ((1ull << lane) - 1ull));
+            slot[at] = p;
+            kvr[at] = kvrow != nullptr ? kvrow[ent * n + p] : (int)(ent * n + p);
+        } else if (p < n) {
+#pragma unroll
+            for (int b = 0; b < KB; ++b) sc[b][p] = -INFINITY;
+        }
+        nl += __popcll(bal);
+    }
+    const int j = lane & 15, g = lane >> 4;
+    float4 qv[KB][NCH];
+#pragma unroll
+    for (int b = 0; b < KB; ++b)
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int ch = j + 16 * c;
+            qv[b][c] = (ch * 4 < dh) ? ld4(qbuf + (r0 + b) * d + h * dh + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    auto krow = [&](int i) -> const T* { return base + (int64_t)kvr[i] * 2 * d + h * dh; };
+
+    for (int i0 = 0; i0 < nl; i0 += 16) {
+        float part[4][KB];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const T* kp = krow(min(i0 + 4 * u + g, nl - 1));
+            float acc[KB];
+#pragma unroll
+            for (int b = 0; b < KB; ++b) acc[b] = 0.0f;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int ch = j + 16 * c;
+                if (ch * 4 < dh) {
+                    const float4 kv = ld4(kp + 4 * ch);
+#pragma unroll
+                    for (int b = 0; b < KB; ++b) {
+                        acc[b] = __builtin_fmaf(qv[b][c].x, kv.x, acc[b]);
+                        acc[b] = __builtin_fmaf(qv[b][c].y, kv.y, acc[b]);
+                        acc[b] = __builtin_fmaf(qv[b][c].z, kv.z, acc[b]);
+                        acc[b] = __builtin_fmaf(qv[b][c].w, kv.w, acc[b]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < KB; ++b) part[u][b] = acc[b];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 4 * u + g;
+#pragma unroll
+            for (int b = 0; b < KB; ++b) {
+                const float tot = group16_sum_butterfly(part[u][b]);
+                if (j == 0 && i < nl) sc[b][slot[i]] = tot * scale;
+            }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+#pragma unroll
+    for (int b = 0; b < KB; ++b) {
+        float sv[MAXP / 64];
+        float m = -INFINITY;
+#pragma unroll
+        for (int i = 0; i < MAXP / 64; ++i) {
+            const int p = lane + 64 * i;
+            sv[i] = p < n ? sc[b][p] : -INFINITY;
+            m = fmaxf(m, sv[i]);
+        }
+        m = wave_max(m);
+        float part = 0.0f;
+#pragma unroll
+        for (int i = 0; i < MAXP / 64; ++i) {
+            const int p = lane + 64 * i;
+            const float e = p < n ? d_exp_le0(sv[i] - m) : 0.0f;
+            sv[i] = e;
+            part = part + e;
+        }
+        const float sum = wave_sum_butterfly(part);
+#pragma unroll
+        for (int i = 0; i < MAXP / 64; ++i) {
+            const int p = lane + 64 * i;
+            if (p < n) sc[b][p] = sv[i] / sum;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+    for (int c0 = lane * VEC; c0 < dh; c0 += 64 * VEC) {
+        float acc[KB][VEC];
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) acc[b][e] = 0.0f;
+        for (int i0 = 0; i0 < nl; i0 += 8) {
+            float v[8][VEC];
+            int pos[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = min(i0 + u, nl - 1);
+                pos[u] = i0 + u < nl ? slot[i] : -1;
+                const T* vp = krow(i) + d + c0;
+                if (VEC == 4) {
+                    const float4 x = ld4(vp);
+                    v[u][0] = x.x; v[u][1 % VEC] = x.y; v[u][2 % VEC] = x.z; v[u][3 % VEC] = x.w;
+                } else if (VEC == 2) {
+                    const float2 x = ld2(vp);
+                    v[u][0] = x.x; v[u][1 % VEC] = x.y;
+                } else {
+                    v[u][0] = ld1(vp);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int b = 0; b < KB; ++b) {
+                    const float wgt = pos[u] >= 0 ? sc[b][pos[u]] : 0.0f;   // beyond the list: weight 0, no effect
+#pragma unroll
+                    for (int e = 0; e < VEC; ++e) acc[b][e] = __builtin_fmaf(wgt, v[u][e], acc[b][e]);
+                }
+        }
+#pragma unroll
+        for (int b = 0; b < KB; ++b)
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) st1(out + (r0 + b) * d + h * dh + c0 + e, acc[b][e]);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+template <typename T, int KB, int NCH, int VEC>
+__global__ __launch_bounds__(256) void attn_cross_group_kernel(const T* __restrict__ base, const int32_t* __restrict__ kvrow,
+                                                               const T* __restrict__ qbuf, const uint8_t* __restrict__ mask,
+                                                               const int32_t* __restrict__ sent, int n, T* __restrict__ out,
+                                                               int64_t n_groups, int d, int heads, int dh, float scale) {
+    __shared__ float sc[4][KB][MAXP];
+    __shared__ int slot[4][MAXP];
+    __shared__ int kvr[4][MAXP];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t gw = (int64_t)blockIdx.x * 4 + w;
+    if (gw >= n_groups * heads) return;          // no workgroup barrier below
+    const int64_t grp = gw / heads;
+    const int h = (int)(gw - grp * heads);
+    const int64_t r0 = grp * KB;
+    const int64_t ent = sent[r0];
+    bool same = true;
+#pragma unroll
+    for (int b = 1; b < KB; ++b) same = same && sent[r0 + b] == ent;
+    if (same) {
+        attend_rows<T, KB, NCH, VEC>(base, kvrow, qbuf, mask, ent, n, out, r0, d, h, dh, scale, sc[w], slot[w], kvr[w], lane);
+    } else {
+        for (int b = 0; b < KB; ++b)
+            attend_rows<T, 1, NCH, VEC>(base, kvrow, qbuf, mask, sent[r0 + b], n, out, r0 + b, d, h, dh, scale, sc[w], slot[w], kvr[w],
+                                        lane);
+    }
+}
+
+template <typename T, int KB>
+int launch_cross_group(const T* kv, const int32_t* kvrow, const T* q, const uint8_t* mask, const int32_t* sent, int64_t n, T* out,
+                       int64_t R, int64_t d, int64_t heads, hipStream_t stream, const char* name) {
+    const int64_t dh = d / heads;
+    const float scale = (float)(1.0 / sqrt((double)dh));
+    const int64_t n_groups = R / KB;
+    const unsigned grid = (unsigned)((n_groups * heads + 3) / 4);
+    const int nch = (int)((dh + 63) / 64);
+    const int vec = (dh % 256 == 0) ? 4 : (dh % 128 == 0) ? 2 : 1;
+#define TST_GROUP_CASE(NCH_, VEC_)                                                                                       \
+    hipLaunchKernelGGL((attn_cross_group_kernel<T, KB, NCH_, VEC_>), dim3(grid), dim3(256), 0, stream, kv, kvrow, q, mask, sent, \
+                       (int)n, out, n_groups, (int)d, (int)heads, (int)dh, scale)
+    if (nch == 1 && vec == 1) TST_GROUP_CASE(1, 1);
+    else if (nch == 2 && vec == 2) TST_GROUP_CASE(2, 2);
+    else if (nch == 2 && vec == 1) TST_GROUP_CASE(2, 1);
+    else return 1;   // not built for this head size: the caller takes the row-per-wave kernel
+#undef TST_GROUP_CASE
+    return tst_after_launch(name);
+}
+
 }  // namespace
 
 extern "C" int tst_attn_self_step_f32(const float* cache, int64_t slab_rows, const int32_t* anc, int64_t anc_ld,
@@ -385,6 +579,28 @@ extern "C" int tst_attn_cross_packed_f32(const float* q, const float* kv, const 
     if (R == 0) return TST_OK;
     return launch_attn<float, false>(kv, 0, kvrow, 0, q, mask, sent, S, out, R, d, heads, (hipStream_t)stream,
                               "tst_attn_cross_packed_f32");
+}
+
+extern "C" int tst_attn_cross_group_f32(const float* q, const float* kv, const uint8_t* mask, const int32_t* sent,
+                                        const int32_t* kvrow, int64_t S, float* out, int64_t R, int64_t d, int64_t heads,
+                                        int64_t group, void* stream) {
+    TST_REQUIRE(q && kv && sent && out, TST_ERR_ARG, "tst_attn_cross_group_f32: null pointer");
+    TST_REQUIRE(R >= 0 && d > 0 && heads > 0 && d % heads == 0 && (d / heads) % 4 == 0 && S > 0 && group >= 1, TST_ERR_ARG,
+                "tst_attn_cross_group_f32: bad sizes");
+    TST_REQUIRE(kvrow == nullptr || mask != nullptr, TST_ERR_ARG, "tst_attn_cross_group_f32: a packed k|v needs the mask");
+    TST_REQUIRE(S <= MAXP, TST_ERR_UNSUPPORTED, "tst_attn_cross_group_f32: at most %d source positions", MAXP);
+    TST_REQUIRE(tst_aligned16(q) && tst_aligned16(kv) && tst_aligned16(out), TST_ERR_ARG, "tst_attn_cross_group_f32: alignment");
+    if (R == 0) return TST_OK;
+    int rc = 1;   // 1: no grouped kernel for this case
+    if (R % group == 0) {
+        const hipStream_t st = (hipStream_t)stream;
+        if (group == 2) rc = launch_cross_group<float, 2>(kv, kvrow, q, mask, sent, S, out, R, d, heads, st, "tst_attn_cross_group_f32");
+        else if (group == 4) rc = launch_cross_group<float, 4>(kv, kvrow, q, mask, sent, S, out, R, d, heads, st, "tst_attn_cross_group_f32");
+        else if (group == 8) rc = launch_cross_group<float, 8>(kv, kvrow, q, mask, sent, S, out, R, d, heads, st, "tst_attn_cross_group_f32");
+    }
+    if (rc != 1) return rc;
+    return launch_attn<float, false>(kv, 0, kvrow, 0, q, mask, sent, S, out, R, d, heads, (hipStream_t)stream,
+                              "tst_attn_cross_group_f32");
 }
 
 // bf16 storage (cache, q, k|v and output), fp32 arithmetic in the same order as the fp32 kernels

@@ -71,7 +71,12 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
                 TST_REQUIRE(L.kv_cross && L.cwo && m->q && sent, TST_ERR_ARG, "tst_tfm_step_run: layer %d cross block incomplete", li);
                 TST_TRY(c.layernorm(m->x, L.ln_cross_g, L.ln_cross_b, m->h));
                 TST_TRY(c.gemm(m->h, d, L.cwq, L.ld_cwq, L.cbq, nullptr, 0, m->q, d, d, d, 0, true));
-                if (m->kvrow != nullptr) {
+                // the caller says that the rows are the beams of a beam search, m->group adjacent rows per sentence
+                const bool grouped = !c.bf16 && m->group > 1 && R % m->group == 0;
+                if (grouped) {
+                    TST_TRY(tst_attn_cross_group_f32((const float*)m->q, (const float*)L.kv_cross, m->mask, sent, m->kvrow, m->S,
+                                                     (float*)m->a, R, d, m->heads, m->group, stream));
+                } else if (m->kvrow != nullptr) {
                     TST_REQUIRE(!c.bf16 && m->mask != nullptr, TST_ERR_ARG, "tst_tfm_step_run: a packed k|v needs fp32 and a mask");
                     TST_TRY(tst_attn_cross_packed_f32((const float*)m->q, (const float*)L.kv_cross, m->mask, sent, m->kvrow, m->S,
                                                       (float*)m->a, R, d, m->heads, stream));

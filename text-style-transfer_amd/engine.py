@@ -12,6 +12,7 @@ A *session* provides:
   ``step(rows, n_rows, t) -> logits``   fp32 GPU tensor [>= n_rows, >= V], unit inner stride
   ``reorder(row_parent, n_rows, identity)``  called after each step with the old row of every new row
   ``takes_soft``      (optional) ``step`` accepts ``soft=`` token distributions [rows, Vp] in place of ``rows.tok``
+  ``rows_per_sentence``  (set by the loop before every step) adjacent rows that belong to one sentence
   ``incremental``     (optional) the session consumes one token per step (KV cache / carried state): a caller-provided
                       prefix is then fed token by token before the loop; otherwise ``step`` reads the prefix from ``rows.hist``
 Rows: step 0 has one row per sentence (row a = sentence a, per-sentence state in rows 0..B-1 of buffers sized
@@ -125,6 +126,7 @@ class DecodeLoop:
         for t in range(T):
             k_in = 1 if t == 0 else k      # rows per sentence going into this step
             R = n_sent * k_in
+            s.rows_per_sentence = k_in     # sessions that share work among the beams of a sentence read this
             if self.gumbel is None:
                 logits = s.step(self.cur, R, pos0 + t)
             else:

@@ -130,9 +130,16 @@ def attn_self_step(cache, anc, pos, out, n_rows, d, heads):
     call('tst_attn_self_step_bf16' if cache.dtype == torch.bfloat16 else 'tst_attn_self_step_f32', _p(cache), cache.shape[1], _p(anc), anc.shape[1], pos, _p(out), n_rows, d, heads, _stream())
 
 
-def attn_cross_step(q, kv, mask, sent, out, n_rows, d, heads, kvrow=None):
+def attn_cross_step(q, kv, mask, sent, out, n_rows, d, heads, kvrow=None, group=None):
     """q [rows, d]; kv [n_sent, S, 2d]; mask [n_sent, S] uint8 or None; sent [rows] int32.
-    With ``kvrow`` ([n_sent, S] int32) ``kv`` is packed, [n_packed, 2d]: the row of (sentence, position) is kvrow[s, p]."""
+    With ``kvrow`` ([n_sent, S] int32) ``kv`` is packed, [n_packed, 2d]: the row of (sentence, position) is kvrow[s, p].
+    ``group`` (fp32): adjacent rows in groups of that size are hypotheses of one sentence (keys / values loaded once)."""
+    if group is not None:
+        _chk(q, torch.float32, 'q'); _chk(kv, torch.float32, 'kv'); _chk(mask, torch.uint8, 'mask'); _chk(sent, torch.int32, 'sent')
+        _chk(out, torch.float32, 'out'); _chk(kvrow, torch.int32, 'kvrow')
+        S = mask.shape[1] if mask is not None else kv.shape[1]
+        call('tst_attn_cross_group_f32', _p(q), _p(kv), _p(mask), _p(sent), _p(kvrow), S, _p(out), n_rows, d, heads, int(group), _stream())
+        return
     dt = torch.bfloat16 if q.dtype == torch.bfloat16 else torch.float32
     _chk(q, dt, 'q'); _chk(kv, dt, 'kv'); _chk(mask, torch.uint8, 'mask'); _chk(sent, torch.int32, 'sent')
     _chk(out, dt, 'out')
@@ -189,7 +196,7 @@ class StepPlan:
     the leading dimension); the plan keeps every tensor alive."""
 
     def __init__(self, *, d, heads, d_ff, V, bf16, n_pos, slab_rows, S, anc_ld, emb, pe, scale, z, mask, ln, wout, bout,
-                 x, h, q, a, ff, logits, layers, eps=1e-5, kvrow=None):
+                 x, h, q, a, ff, logits, layers, eps=1e-5, kvrow=None, group=1):
         self._keep = [kvrow, emb, pe, z, mask, ln, wout, bout, x, h, q, a, ff, logits, layers]
         n = len(layers)
         self._layers = (_lib.TstTfmLayer * n)()
@@ -201,7 +208,7 @@ class StepPlan:
                 else:
                     setattr(dst, name, _p(L.get(name)))
         self.c = _lib.TstTfmStep(
-            n_layers=n, d=d, heads=heads, d_ff=d_ff, V=V, bf16=int(bool(bf16)), n_pos=n_pos, slab_rows=slab_rows, S=S, anc_ld=anc_ld,
+            n_layers=n, d=d, heads=heads, d_ff=d_ff, V=V, bf16=int(bool(bf16)), group=int(group), n_pos=n_pos, slab_rows=slab_rows, S=S, anc_ld=anc_ld,
             emb=_p(emb), pe=_p(pe), scale=float(scale), eps=float(eps), z=_p(z), mask=_p(mask), kvrow=_p(kvrow), ln_g=_p(ln[0]), ln_b=_p(ln[1]),
             wout=_p(wout), bout=_p(bout), ld_wout=wout.stride(0), x=_p(x), h=_p(h), q=_p(q), a=_p(a), ff=_p(ff), logits=_p(logits),
             ld_logits=logits.stride(0), layers=self._layers)

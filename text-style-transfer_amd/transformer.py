@@ -263,6 +263,7 @@ class TransformerSession:
         self.scale = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
         self.max_len = max_len
         self._plans = {}
+        self.rows_per_sentence = 1   # adjacent rows that belong to one sentence in the coming step (the loop updates it)
 
     def reorder(self, row_parent, n_rows, identity):
         pass  # the KV cache is addressed through the ancestor table; nothing moves
@@ -292,6 +293,7 @@ class TransformerSession:
         the step are issued by one native call (two when the vocabulary projection is being timed)."""
         dec = self.dec
         plan = self._plan(rows.anc.shape[1])
+        plan.c.group = self.rows_per_sentence      # set by the decode loop: 1 at the first step, then the beam size
         body = K.STEP_LAYERS
         if soft is None:
             body |= K.STEP_EMBED
