@@ -4,7 +4,6 @@ tests/golden/postprocess.json by tests/golden/make_golden.py."""
 import json
 import os
 
-import numpy as np
 import pytest
 import torch
 

@@ -6,7 +6,6 @@ every non-padding (sentence, position) is a row whose keys/values are the non-pa
 sentence.
 """
 import math
-from collections import OrderedDict
 
 import torch
 

@@ -13,7 +13,6 @@ the bf16 matrix cores, fp32 residual stream, LayerNorm statistics, softmax and s
 fixed-order fp32 kernels.
 """
 import math
-from collections import OrderedDict
 
 import torch
 
