@@ -112,7 +112,6 @@ def test_foreign_model_under_beam_search(T):
     """A model that is not from this package (the torch specification on the GPU, whole-prefix calls): beam search
     reorders its inputs and mask through index_select; same sequences as the native model."""
     tmodel, model, vocab, encs, mask = mt_case(T, 120, 6, 8, 1.0, 27)
-    import types
     dec = tmodel.decoder.cuda()
     st = T.InferenceState({'model': dec, 'inputs': torch.from_numpy(encs).cuda(), 'enc_mask': torch.from_numpy(mask).cuda(),
                            'vocab': vocab, 'max_len': 10, 'beam_size': 3})
