@@ -273,8 +273,7 @@ __global__ __launch_bounds__(256) void attn_step_h64_kernel(
             s[i][q] = p < n ? sc[w][g][p] : -INFINITY;
             m = fmaxf(m, s[i][q]);
         }
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    m = group16_max(m);
     float part[4] = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
     for (int i = 0; i < MAXP / 64; ++i)

@@ -11,13 +11,20 @@ namespace {
 // (value desc, index asc) ordering
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) { return v > bv || (v == bv && i < bi); }
 
+template <int OFF>
+__device__ __forceinline__ void argmax_step(float& v, int& i) {
+    const float ov = lane_xor<OFF>(v);
+    const int oi = lane_xor_i<OFF>(i);
+    if (better(ov, oi, v, i)) { v = ov; i = oi; }
+}
+
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) {
-        const float ov = __shfl_xor(v, off, 64);
-        const int oi = __shfl_xor(i, off, 64);
-        if (better(ov, oi, v, i)) { v = ov; i = oi; }
-    }
+    argmax_step<32>(v, i);
+    argmax_step<16>(v, i);
+    argmax_step<8>(v, i);
+    argmax_step<4>(v, i);
+    argmax_step<2>(v, i);
+    argmax_step<1>(v, i);
 }
 
 // block-wide (256 threads) argmax; result valid in every thread. red_* are LDS arrays of 4.

@@ -30,24 +30,61 @@ static inline bool tst_aligned16(const void* p) { return (reinterpret_cast<uintp
 
 #define TST_WAVE 64
 
+// Value of lane (lane ^ OFF), OFF a power of two below 64, without the LDS crossbar of ds_bpermute (__shfl_xor):
+// DPP controls inside a row of 16 lanes, v_permlane16_swap / v_permlane32_swap (gfx950) across rows and halves.
+// Checked lane by lane against __shfl_xor on the device (tools/probe/probe_lane_xor.hip).
+template <int OFF>
+__device__ __forceinline__ int lane_xor_i(int x) {
+    static_assert(OFF == 1 || OFF == 2 || OFF == 4 || OFF == 8 || OFF == 16 || OFF == 32, "lane_xor: 1, 2, 4, 8, 16 or 32");
+    if (OFF == 1) return __builtin_amdgcn_update_dpp(x, x, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    if (OFF == 2) return __builtin_amdgcn_update_dpp(x, x, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    if (OFF == 4) {
+        int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xf, 0x5, false);           // row_shl:4 into banks 0, 2: lane i <- i + 4
+        return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xf, 0xa, false);            // row_shr:4 into banks 1, 3: lane i <- i - 4
+    }
+    if (OFF == 8) return __builtin_amdgcn_update_dpp(x, x, 0x128, 0xf, 0xf, false);  // row_ror:8
+    if (OFF == 16) {   // rows 0 <-> 1 and 2 <-> 3
+        const auto r = __builtin_amdgcn_permlane16_swap((unsigned)x, (unsigned)x, false, false);
+        return (int)(((threadIdx.x >> 4) & 1) ? r[0] : r[1]);
+    }
+    const auto r = __builtin_amdgcn_permlane32_swap((unsigned)x, (unsigned)x, false, false);   // lanes 0..31 <-> 32..63
+    return (int)(((threadIdx.x >> 5) & 1) ? r[0] : r[1]);
+}
+template <int OFF>
+__device__ __forceinline__ float lane_xor(float v) { return __int_as_float(lane_xor_i<OFF>(__float_as_int(v))); }
+
 // sum over the 64 lanes of a wave: for off = 32,16,..,1: v = v + v(lane ^ off); every lane gets the total
 __device__ __forceinline__ float wave_sum_butterfly(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    v = v + lane_xor<32>(v);
+    v = v + lane_xor<16>(v);
+    v = v + lane_xor<8>(v);
+    v = v + lane_xor<4>(v);
+    v = v + lane_xor<2>(v);
+    v = v + lane_xor<1>(v);
     return v;
 }
 
 // the same within aligned groups of 16 lanes (off = 8,4,2,1)
 __device__ __forceinline__ float group16_sum_butterfly(float v) {
-#pragma unroll
-    for (int off = 8; off >= 1; off >>= 1) v = v + __shfl_xor(v, off, 64);
+    v = v + lane_xor<8>(v);
+    v = v + lane_xor<4>(v);
+    v = v + lane_xor<2>(v);
+    v = v + lane_xor<1>(v);
+    return v;
+}
+
+__device__ __forceinline__ float group16_max(float v) {
+    v = fmaxf(v, lane_xor<8>(v));
+    v = fmaxf(v, lane_xor<4>(v));
+    v = fmaxf(v, lane_xor<2>(v));
+    v = fmaxf(v, lane_xor<1>(v));
     return v;
 }
 
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-    return v;
+    v = fmaxf(v, lane_xor<32>(v));
+    v = fmaxf(v, lane_xor<16>(v));
+    return group16_max(v);
 }
 
 // exp(x): 0 for x < -87 (and for NaN), x clamped to 88 above.  Branch-free: the argument is clamped into
