@@ -34,6 +34,20 @@ def _check_logits(logits, n_rows, V):
                          % (n_rows, V, tuple(logits.shape)))
 
 
+_LP_CACHE = {}
+
+
+def _lp_on_device(max_len, alpha, dev):
+    """The length-penalty table on the device, kept per (length, alpha, device): a decode call would otherwise pay a
+    host-to-device copy for a few hundred bytes that never change."""
+    key = (max_len, alpha, str(dev))
+    if key not in _LP_CACHE:
+        if len(_LP_CACHE) > 64:
+            _LP_CACHE.clear()
+        _LP_CACHE[key] = length_penalty_table(max_len, alpha).to(dev)
+    return _LP_CACHE[key]
+
+
 class DecodeLoop:
     def __init__(self, session, n_sent, beam, max_len, bos, eos, pad, alpha=0.0, device=None, sample=None, gumbel=None,
                  prefix=None):
@@ -73,15 +87,13 @@ class DecodeLoop:
             self.cur.nemit[:n_sent] = self.pos0
             if self.cur.anc is not None and self.pos0 > 0:   # prefix positions live in the sentence's own row
                 self.cur.anc[:n_sent, :self.pos0] = self.cur.sent[:n_sent].unsqueeze(1)
-        self.lp = length_penalty_table(self.Ttot, alpha).to(dev)
+        self.lp = _lp_on_device(self.Ttot, float(alpha), dev)
         i32 = dict(dtype=torch.int32, device=dev)
         self.out_tok = torch.full((n_sent, self.Ttot + 1), pad, **i32)
-        self.out_len = torch.zeros(n_sent, **i32)
         self.out_score = torch.zeros(n_sent, dtype=torch.float32, device=dev)
-        self.scratch = torch.zeros(2 * n_sent, **i32)
-        self.row_parent = torch.zeros(R, **i32)
-        self.n_alive = torch.zeros(1, **i32)
-        self.am = torch.zeros(R, **i32)
+        shapes = [(n_sent,), (2 * n_sent,), (R,), (1,), (R,)]      # one allocation for the small int32 arrays
+        arena = torch.zeros(K._arena_size(shapes), **i32)
+        self.out_len, self.scratch, self.row_parent, self.n_alive, self.am = K._carve(arena, shapes)
         self.top_val = self.top_idx = self.lse = None
         if beam > 1:
             self.top_val = torch.zeros((R, beam), dtype=torch.float32, device=dev)

@@ -252,7 +252,7 @@ class InferenceState:
 def simple_inference(model, z, vocab, max_len=100, eos_token='<eos>'):
     """``/root/reference/src/inference.py:170-181``: greedy decode, result as ``list[list[int]]``."""
     state = InferenceState({'model': model, 'inputs': z, 'vocab': vocab, 'max_len': max_len, 'eos_token': eos_token})
-    state.inference()
-    lens = state.loop.out_len.cpu().tolist()
-    toks = state.loop.out_tok.cpu().tolist()
+    loop = state._run(0)                     # the packed result: two device-to-host copies for the whole batch
+    lens = loop.out_len.cpu().tolist()
+    toks = loop.out_tok.cpu().tolist()
     return [row[:n] for row, n in zip(toks, lens)]

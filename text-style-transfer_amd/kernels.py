@@ -271,19 +271,41 @@ class SelectPlan:
         call('tst_select_step_run', self.c, cur.struct(), nxt.struct(), n_sent, k_in, step, sample_step, int(last_step), _stream())
 
 
+def _carve(arena, shapes):
+    """Views of the given shapes into a 1-D arena, each starting at a multiple of 64 elements (256 bytes)."""
+    out, at = [], 0
+    for shape in shapes:
+        n = 1
+        for x in shape:
+            n *= x
+        out.append(arena[at:at + n].view(shape))
+        at += (n + 63) // 64 * 64
+    return out
+
+
+def _arena_size(shapes):
+    total = 0
+    for shape in shapes:
+        n = 1
+        for x in shape:
+            n *= x
+        total += (n + 63) // 64 * 64
+    return total
+
+
 class RowState:
-    """Per-row decode state on the device (``tst_rows``): token history, ancestor table, scores, flags."""
+    """Per-row decode state on the device (``tst_rows``): token history, ancestor table, scores, flags.  The int32
+    arrays are views into one allocation (a decode call makes two of these objects; at small batches the time to
+    allocate and clear many little tensors is a visible part of the call)."""
 
     def __init__(self, rows, T, device, with_anc, fill_token):
-        i32 = dict(dtype=torch.int32, device=device)
-        self.hist = torch.full((rows, T + 1), fill_token, **i32)
-        self.anc = torch.zeros((rows, T), **i32) if with_anc else None
-        self.sent = torch.zeros(rows, **i32)
-        self.tok = torch.zeros(rows, **i32)
+        shapes = [(rows, T + 1), (rows, T) if with_anc else (0,), (rows,), (rows,), (rows,), (rows,)]
+        arena = torch.zeros(_arena_size(shapes), dtype=torch.int32, device=device)
+        self.hist, anc, self.sent, self.tok, self.fin, self.nemit = _carve(arena, shapes)
+        self.anc = anc if with_anc else None
+        if fill_token != 0:
+            self.hist.fill_(fill_token)
         self.score = torch.zeros(rows, dtype=torch.float32, device=device)
-        self.fin = torch.zeros(rows, **i32)
-        self.nemit = torch.zeros(rows, **i32)
-
         self._struct = None
 
     def struct(self):
@@ -297,12 +319,10 @@ class Selection:
     """Output arrays of the select kernels (one entry per new row slot)."""
 
     def __init__(self, rows, device):
-        i32 = dict(dtype=torch.int32, device=device)
-        self.parent = torch.zeros(rows, **i32)
-        self.tok = torch.zeros(rows, **i32)
+        shapes = [(rows,)] * 4
+        arena = torch.zeros(_arena_size(shapes), dtype=torch.int32, device=device)
+        self.parent, self.tok, self.fin, self.nemit = _carve(arena, shapes)
         self.score = torch.zeros(rows, dtype=torch.float32, device=device)
-        self.fin = torch.zeros(rows, **i32)
-        self.nemit = torch.zeros(rows, **i32)
 
     def ptrs(self):
         return _p(self.parent), _p(self.tok), _p(self.score), _p(self.fin), _p(self.nemit)
