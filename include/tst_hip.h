@@ -30,7 +30,7 @@ extern "C" {
 
 /* ABI version of this header (major * 100 + minor): 101 = 100 + tst_gemm_skinny_f32, tst_attn_cross_packed_f32,
  * tst_tfm_step_run, tst_gru_step_run, tst_gru_reorder_run, tst_select_step_run,
- * tst_attn_cross_group_f32 (additions only). */
+ * tst_attn_cross_group_f32, tst_ln_gemm_f32 (additions only). */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
@@ -64,6 +64,14 @@ int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw,
  * element is the same k-ordered fma chain); exported so that tests and tuning can reach it at any size. */
 int tst_gemm_skinny_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res,
                         int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, int strip, void* stream);
+
+/* C[M][N] = epilogue(bias[n] + sum_k LayerNorm(x)[m][k] * Wt[k][n]): tst_layernorm_f32 over rows of K floats followed by
+ * tst_gemm_mfma_f32 (act as there, no residual), with identical results.  For small problems (K = 256 or 512 and at
+ * most 2048 tiles of 16 x 16 in C) it is ONE kernel that never stores the normalised rows; otherwise the two entry
+ * points run one after the other and h [M][K] (caller's scratch, always required, contents unspecified afterwards)
+ * receives the normalised rows.  x is [M][K] contiguous. */
+int tst_ln_gemm_f32(const float* x, const float* gamma, const float* beta, float eps, float* h, const float* Wt, int64_t ldw,
+                    const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream);
 
 /* y = LayerNorm(x) as above with the result rounded to bf16 (the operand of a following bf16 GEMM). */
 int tst_layernorm_f32_bf16(const float* x, const float* gamma, const float* beta, float eps, void* y, int64_t R, int64_t d,

@@ -41,6 +41,8 @@ def test_argument_errors_are_reported_not_crashed():
         _lib.call('tst_gemm_mfma_f32', 16, 6, 16, 4, None, None, 0, 16, 4, 1, 4, 6, 0, None)
     with pytest.raises(_lib.TstError, match='1 <= k'):
         _lib.call('tst_logsoftmax_topk_f32', 16, 100, 1, 100, 9, 16, 16, 16, None)
+    with pytest.raises(_lib.TstError, match='tst_ln_gemm_f32: null pointer'):
+        _lib.call('tst_ln_gemm_f32', 16, 16, 16, 1e-5, None, 16, 4, None, 16, 4, 1, 4, 4, 0, None)
     with pytest.raises(_lib.TstError, match='strip must be'):
         _lib.call('tst_gemm_skinny_f32', 16, 4, 16, 4, None, None, 0, 16, 4, 1, 4, 4, 0, 3, None)
     # the whole-step launcher checks its plan before the first launch

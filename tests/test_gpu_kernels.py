@@ -65,6 +65,29 @@ def test_gemm_small_problem_kernel_bit_exact(K, M, N, K_, bias, act, res, strip)
         _gemm_case(K, M, N, K_, bias, act, res, strip=strip, odd_ldc=True)
 
 
+@pytest.mark.parametrize('M,N,K_,act', [(1, 256, 256, 0), (37, 768, 256, 0), (256, 1024, 256, 1), (300, 90, 256, 1), (640, 768, 256, 0),
+                                        (1000, 768, 256, 0), (130, 1536, 512, 0), (70, 2048, 512, 1), (3000, 1024, 256, 1),
+                                        (50, 200, 64, 0)])
+def test_layernorm_gemm_bit_exact(K, M, N, K_, act):
+    """LayerNorm + product as one entry point: the fused small-problem kernel (row lengths 256 and 512, all strip widths),
+    and the two-kernel route for everything else, against the canonical LayerNorm followed by the canonical product."""
+    r = rs(M + N + K_)
+    x = (r.standard_normal((M, K_)) * 2 + 0.5).astype(np.float32)
+    g, b = r.standard_normal(K_).astype(np.float32), r.standard_normal(K_).astype(np.float32)
+    W = r.standard_normal((K_, N)).astype(np.float32)
+    bias = r.standard_normal(N).astype(np.float32)
+    ldw = (N + 3) // 4 * 4
+    Wd = torch.zeros((K_, ldw), dtype=torch.float32, device='cuda')
+    Wd[:, :N] = dev(W)
+    out = torch.full((M, ldw), 7.0, dtype=torch.float32, device='cuda')
+    h = torch.empty((M, K_), dtype=torch.float32, device='cuda')
+    K.ln_gemm(dev(x), dev(g), dev(b), h, Wd[:, :N], dev(bias), out, M, n_cols=N, act=act)
+    want = C.gemm(C.layernorm(x, g, b), W, bias, None, act)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, :N], want)
+    assert (got[:, N:] == 7.0).all()
+
+
 def test_gemm_in_place_residual_and_row_prefix(K):
     r = rs(3)
     A = r.standard_normal((200, 64)).astype(np.float32)

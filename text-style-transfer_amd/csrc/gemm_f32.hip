@@ -378,6 +378,153 @@ void launch_skinny(const float* A, int64_t lda, const float* Wt, int64_t ldw, co
 #undef TST_SK_LAUNCH
 }
 
+// LayerNorm folded into the small-problem kernel: C = epilogue(LayerNorm(x) * Wt + bias) for K = 256 or 512 (the row
+// length).  A wave holds its 16 rows of x completely in registers (K / 16 float4 per lane), computes the statistics in
+// exactly the order of layernorm_kernel (64 interleaved partial sums, partial = float4 chunk % 64, xor-butterfly 32..1;
+// lane (r, kq) owns chunks 4 c + kq, so the butterfly levels 32, 16, 8, 4 pair registers of the lane and levels 2, 1 pair
+// lanes 32 and 16 apart), normalises in place and multiplies.  Every wave of a row strip repeats the statistics: a few
+// hundred VALU instructions against a kernel launch and a round trip of the normalised rows through memory.
+template <int NT, int KCH, bool RELU>
+__global__ __launch_bounds__(64) void gemm_f32_skinny_ln_kernel(const float* __restrict__ X, int64_t ldx, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float eps, const float* __restrict__ W,
+                                                                int64_t ldw, const float* __restrict__ bias, float* C, int64_t ldc,
+                                                                int M, int N, int tiles_n, int vec_store) {
+    typedef typename SkVec<NT>::type wvec;
+    constexpr int K = 16 * KCH;
+    constexpr int BC = NT == 4 ? 4 : 8;            // 16-k chunks of Wt loaded ahead (64 or 128 k)
+    const int lane = threadIdx.x, r = lane & 15, kq = lane >> 4;
+    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x % tiles_n;
+    const int m0 = tm * 16, n0 = tn * 16 * NT;
+    const int col0 = n0 + NT * r;
+    const float* x_row = X + (int64_t)min(m0 + r, M - 1) * ldx;
+    const float* w_col = W + min(col0, (int)ldw - NT);
+
+    wvec b_cur[4 * BC], b_nxt[4 * BC];
+    auto load_b = [&](wvec* bv, int c0) {
+#pragma unroll
+        for (int s = 0; s < 4 * BC; ++s) bv[s] = *reinterpret_cast<const wvec*>(w_col + (int64_t)(16 * c0 + 4 * s + kq) * ldw);
+    };
+    load_b(b_cur, 0);                              // in flight during the normalisation
+
+    float4 a[KCH];                                 // chunk c: elements 16 c + 4 kq .. + 3 of the lane's row
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) a[c] = *reinterpret_cast<const float4*>(x_row + 16 * c + 4 * kq);
+    // 64 partials per row: partial (4 c + kq) % 64 = 4 (c % 16) + kq collects chunks c, c + 16, ... in ascending order
+    auto row_total = [&](float (&p)[16]) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) p[c] = p[c] + p[c + 8];      // butterfly level 32 (chunk ^ 32 <-> c ^ 8)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) p[c] = p[c] + p[c + 4];      // 16
+#pragma unroll
+        for (int c = 0; c < 2; ++c) p[c] = p[c] + p[c + 2];      // 8
+        float v = p[0] + p[1];                                   // 4
+        v = v + lane_xor<32>(v);                                 // 2 (kq ^ 2)
+        v = v + lane_xor<16>(v);                                 // 1 (kq ^ 1)
+        return v;
+    };
+    float p[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float q = 0.0f;
+#pragma unroll
+        for (int c = j; c < KCH; c += 16) { q = q + a[c].x; q = q + a[c].y; q = q + a[c].z; q = q + a[c].w; }
+        p[j] = q;
+    }
+    const float dlen = (float)K;
+    const float mean = row_total(p) / dlen;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        float q = 0.0f;
+#pragma unroll
+        for (int c = j; c < KCH; c += 16) {
+            float t;
+            t = a[c].x - mean; q = __builtin_fmaf(t, t, q);
+            t = a[c].y - mean; q = __builtin_fmaf(t, t, q);
+            t = a[c].z - mean; q = __builtin_fmaf(t, t, q);
+            t = a[c].w - mean; q = __builtin_fmaf(t, t, q);
+        }
+        p[j] = q;
+    }
+    const float var = row_total(p) / dlen;
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int c = 0; c < KCH; ++c) {
+        const float4 gg = *reinterpret_cast<const float4*>(gamma + 16 * c + 4 * kq);
+        const float4 bb = *reinterpret_cast<const float4*>(beta + 16 * c + 4 * kq);
+        a[c].x = __builtin_fmaf((a[c].x - mean) * rstd, gg.x, bb.x);
+        a[c].y = __builtin_fmaf((a[c].y - mean) * rstd, gg.y, bb.y);
+        a[c].z = __builtin_fmaf((a[c].z - mean) * rstd, gg.z, bb.z);
+        a[c].w = __builtin_fmaf((a[c].w - mean) * rstd, gg.w, bb.w);
+    }
+
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const float b = (bias != nullptr && col0 + j < N) ? bias[col0 + j] : 0.0f;
+        acc[j] = f32x4{b, b, b, b};
+    }
+    auto mfma_chunks = [&](const float4* ac, wvec* bv) {   // BC chunks of 16 k: transpose (see gemm_f32_skinny_kernel), multiply
+#pragma unroll
+        for (int c = 0; c < BC; ++c) {
+            const unsigned x0 = __float_as_uint(ac[c].x), x1 = __float_as_uint(ac[c].y), x2 = __float_as_uint(ac[c].z),
+                           x3 = __float_as_uint(ac[c].w);
+            const auto p02 = __builtin_amdgcn_permlane32_swap(x0, x2, false, false);
+            const auto p13 = __builtin_amdgcn_permlane32_swap(x1, x3, false, false);
+            const auto q01 = __builtin_amdgcn_permlane16_swap(p02[0], p13[0], false, false);
+            const auto q23 = __builtin_amdgcn_permlane16_swap(p02[1], p13[1], false, false);
+            const float av[4] = {__uint_as_float(q01[0]), __uint_as_float(q01[1]), __uint_as_float(q23[0]), __uint_as_float(q23[1])};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], sk_get<NT>(bv[4 * c + s], j), acc[j], 0, 0, 0);
+        }
+    };
+    static_assert(KCH % (2 * BC) == 0, "row length must be a multiple of two Wt chunks");
+#pragma unroll
+    for (int c0 = 0; c0 < KCH; c0 += 2 * BC) {
+        load_b(b_nxt, c0 + BC);
+        mfma_chunks(&a[c0], b_cur);
+        if (c0 + 2 * BC < KCH) load_b(b_cur, c0 + 2 * BC);
+        mfma_chunks(&a[c0 + BC], b_nxt);
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = m0 + 4 * kq + i;
+        if (row >= M) continue;
+        float v[NT];
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            v[j] = acc[j][i];
+            if (RELU) v[j] = v[j] > 0.0f ? v[j] : 0.0f;
+        }
+        float* cp = C + (int64_t)row * ldc + col0;
+        if (NT > 1 && vec_store && col0 + NT <= N) {
+            if (NT == 2) *reinterpret_cast<float2*>(cp) = make_float2(v[0], v[NT - 1]);
+            if (NT == 4) *reinterpret_cast<float4*>(cp) = make_float4(v[0], v[1 % NT], v[2 % NT], v[3 % NT]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+                if (col0 + j < N) cp[j] = v[j];
+        }
+    }
+}
+
+template <int NT>
+void launch_skinny_ln(const float* X, int64_t ldx, const float* gamma, const float* beta, float eps, const float* Wt, int64_t ldw,
+                      const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st) {
+    const int64_t tiles_m = (M + 15) / 16, tiles_n = (N + 16 * NT - 1) / (16 * NT);
+    const dim3 grid((unsigned)(tiles_m * tiles_n));
+    const int vec_store = ldc % NT == 0 && (uintptr_t)C % (4 * NT) == 0;
+#define TST_SKLN_LAUNCH(KCH_, RL)                                                                                                  \
+    hipLaunchKernelGGL((gemm_f32_skinny_ln_kernel<NT, KCH_, RL>), grid, dim3(64), 0, st, X, ldx, gamma, beta, eps, Wt, ldw, bias, C, \
+                       ldc, (int)M, (int)N, (int)tiles_n, vec_store)
+    if (K == 256) { if (act == 1) TST_SKLN_LAUNCH(16, true); else TST_SKLN_LAUNCH(16, false); }
+    else          { if (act == 1) TST_SKLN_LAUNCH(32, true); else TST_SKLN_LAUNCH(32, false); }
+#undef TST_SKLN_LAUNCH
+}
+
 int check_gemm_args(const char* who, const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* res, int64_t ldr,
                     float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act) {
     TST_REQUIRE(A && Wt && C, TST_ERR_ARG, "%s: null pointer", who);
@@ -405,6 +552,26 @@ extern "C" int tst_gemm_skinny_f32(const float* A, int64_t lda, const float* Wt,
     else if (strip == 2) launch_skinny<2>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
     else launch_skinny<4>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
     return tst_after_launch("tst_gemm_skinny_f32");
+}
+
+extern "C" int tst_ln_gemm_f32(const float* x, const float* gamma, const float* beta, float eps, float* h, const float* Wt,
+                               int64_t ldw, const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act,
+                               void* stream) {
+    TST_REQUIRE(x && gamma && beta && h, TST_ERR_ARG, "tst_ln_gemm_f32: null pointer");
+    const int rc = check_gemm_args("tst_ln_gemm_f32", x, K, Wt, ldw, nullptr, 0, C, ldc, M, N, K, act);
+    if (rc != TST_OK) return rc;
+    TST_REQUIRE(tst_aligned16(gamma) && tst_aligned16(beta) && tst_aligned16(h), TST_ERR_ARG, "tst_ln_gemm_f32: alignment");
+    if (M == 0) return TST_OK;
+    const int64_t tiles16 = ((M + 15) / 16) * ((N + 15) / 16);
+    if ((K == 256 || K == 512) && tiles16 <= 2048) {   // small: LayerNorm inside the one-wave-per-strip kernel
+        const hipStream_t st = (hipStream_t)stream;
+        if (tiles16 <= 768) launch_skinny_ln<1>(x, K, gamma, beta, eps, Wt, ldw, bias, C, ldc, M, N, K, act, st);
+        else launch_skinny_ln<2>(x, K, gamma, beta, eps, Wt, ldw, bias, C, ldc, M, N, K, act, st);
+        return tst_after_launch("tst_ln_gemm_f32");
+    }
+    const int rc2 = tst_layernorm_f32(x, gamma, beta, eps, h, M, K, stream);
+    if (rc2 != TST_OK) return rc2;
+    return tst_gemm_mfma_f32(h, K, Wt, ldw, bias, nullptr, 0, C, ldc, M, N, K, act, stream);
 }
 
 extern "C" int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias,

@@ -15,6 +15,17 @@ struct StepCtx {
         return bf16 ? tst_layernorm_f32_bf16(x, g, b, m->eps, y, R, m->d, stream)
                     : tst_layernorm_f32(x, g, b, m->eps, (float*)y, R, m->d, stream);
     }
+    // out = epilogue(LayerNorm(x) * w + bias) with the output in the activation type; fp32: one entry point (one kernel
+    // when the problem is small), bf16: LayerNorm into h, then the product
+    int ln_gemm(const float* g, const float* b, const void* w, int64_t ldw, const float* bias, void* out, int64_t ldo, int64_t N,
+                int act) const {
+        if (!bf16)
+            return tst_ln_gemm_f32(m->x, g, b, m->eps, (float*)m->h, (const float*)w, ldw, bias, (float*)out, ldo, R, N, m->d, act,
+                                   stream);
+        const int rc = layernorm(m->x, g, b, m->h);
+        if (rc != TST_OK) return rc;
+        return gemm(m->h, m->d, w, ldw, bias, nullptr, 0, out, ldo, N, m->d, act, true);
+    }
     // out = epilogue(a * w + bias); out_lo: the output has the activation type (bf16 when the model is), else fp32
     int gemm(const void* a, int64_t lda, const void* w, int64_t ldw, const float* bias, const float* res, int64_t ldr, void* out,
              int64_t ldo, int64_t N, int64_t K, int act, bool out_lo) const {
@@ -61,16 +72,14 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
             const tst_tfm_layer& L = m->layers[li];
             TST_REQUIRE(L.cache && L.wqkv && L.wo && L.w1 && L.w2, TST_ERR_ARG, "tst_tfm_step_run: layer %d incomplete", li);
             char* slab = (char*)L.cache + t * m->slab_rows * 3 * d * esz;   // the rows of position t
-            TST_TRY(c.layernorm(m->x, L.ln_self_g, L.ln_self_b, m->h));
-            TST_TRY(c.gemm(m->h, d, L.wqkv, L.ld_wqkv, L.bqkv, nullptr, 0, slab, 3 * d, 3 * d, d, 0, true));
+            TST_TRY(c.ln_gemm(L.ln_self_g, L.ln_self_b, L.wqkv, L.ld_wqkv, L.bqkv, slab, 3 * d, 3 * d, 0));
             TST_TRY(c.bf16 ? tst_attn_self_step_bf16(L.cache, m->slab_rows, anc, m->anc_ld, t, m->a, R, d, m->heads, stream)
                            : tst_attn_self_step_f32((const float*)L.cache, m->slab_rows, anc, m->anc_ld, t, (float*)m->a, R, d,
                                                     m->heads, stream));
             TST_TRY(c.gemm(m->a, d, L.wo, L.ld_wo, L.bo, m->x, d, m->x, d, d, d, 0, false));
             if (L.cwq != nullptr) {
                 TST_REQUIRE(L.kv_cross && L.cwo && m->q && sent, TST_ERR_ARG, "tst_tfm_step_run: layer %d cross block incomplete", li);
-                TST_TRY(c.layernorm(m->x, L.ln_cross_g, L.ln_cross_b, m->h));
-                TST_TRY(c.gemm(m->h, d, L.cwq, L.ld_cwq, L.cbq, nullptr, 0, m->q, d, d, d, 0, true));
+                TST_TRY(c.ln_gemm(L.ln_cross_g, L.ln_cross_b, L.cwq, L.ld_cwq, L.cbq, m->q, d, d, 0));
                 // the caller says that the rows are the beams of a beam search, m->group adjacent rows per sentence
                 const bool grouped = !c.bf16 && m->group > 1 && R % m->group == 0;
                 if (grouped) {
@@ -87,8 +96,7 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
                 }
                 TST_TRY(c.gemm(m->a, d, L.cwo, L.ld_cwo, L.cbo, m->x, d, m->x, d, d, d, 0, false));
             }
-            TST_TRY(c.layernorm(m->x, L.ln_ff_g, L.ln_ff_b, m->h));
-            TST_TRY(c.gemm(m->h, d, L.w1, L.ld_w1, L.b1, nullptr, 0, m->ff, m->d_ff, m->d_ff, d, 1, true));
+            TST_TRY(c.ln_gemm(L.ln_ff_g, L.ln_ff_b, L.w1, L.ld_w1, L.b1, m->ff, m->d_ff, m->d_ff, 1));
             TST_TRY(c.gemm(m->ff, m->d_ff, L.w2, L.ld_w2, L.b2, m->x, d, m->x, d, d, m->d_ff, 0, false));
         }
         TST_TRY(c.layernorm(m->x, m->ln_g, m->ln_b, m->h));

@@ -81,6 +81,22 @@ def layernorm(x, gamma, beta, out, n_rows, eps=1e-5):
     call(name, _p(x), _p(gamma), _p(beta), float(eps), _p(out), n_rows, d, _stream())
 
 
+def ln_gemm(x, gamma, beta, h, wt, bias, out, n_rows, n_cols=None, act=0, eps=1e-5):
+    """out[:n_rows, :N] = epilogue(LayerNorm(x[:n_rows]) @ wt[:, :N] + bias); ``h`` [rows, K] is scratch (it receives the
+    normalised rows only when the problem is too large for the fused kernel)."""
+    for t, nm in ((x, 'x'), (gamma, 'gamma'), (beta, 'beta'), (h, 'h')):
+        _chk(t, torch.float32, nm)
+    for t, nm in ((wt, 'wt'), (out, 'out'), (bias, 'bias')):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1):
+            raise ValueError('%s must be an fp32 GPU tensor with unit inner stride' % nm)
+    K = x.shape[1]
+    N = wt.shape[1] if n_cols is None else n_cols
+    assert wt.shape[0] == K and h.shape[1] == K and out.shape[1] >= N and min(x.shape[0], h.shape[0], out.shape[0]) >= n_rows
+    assert gamma.numel() == K and beta.numel() == K and (bias is None or bias.numel() >= N)
+    call('tst_ln_gemm_f32', _p(x), _p(gamma), _p(beta), float(eps), _p(h), _p(wt), wt.stride(0), _p(bias), _p(out), out.stride(0),
+         n_rows, N, K, int(act), _stream())
+
+
 def add_rows(x, z, idx, n_rows):
     """x[r] += z[idx[r]]"""
     _chk(x, torch.float32, 'x'); _chk(z, torch.float32, 'z'); _chk(idx, torch.int32, 'idx')
