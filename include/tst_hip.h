@@ -30,7 +30,8 @@ extern "C" {
 
 /* ABI version of this header (major * 100 + minor): 101 = 100 + tst_gemm_skinny_f32, tst_attn_cross_packed_f32,
  * tst_tfm_step_run, tst_gru_step_run, tst_gru_reorder_run, tst_select_step_run,
- * tst_attn_cross_group_f32, tst_ln_gemm_f32 (additions only). */
+ * tst_attn_cross_group_f32, tst_ln_gemm_f32,
+ * tst_greedy_retire_compact (additions only). */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
@@ -215,12 +216,20 @@ int tst_greedy_select(const int32_t* argmax_tok, int64_t n_rows, int32_t eos, in
  * their order; their rows are gathered from `cur` through sel_parent into `nxt`, the new token is
  * appended to hist and the parent row index to anc (skipped when cur->anc is NULL); row_parent[new row]
  * = old row, for callers that carry further per-row state.  scratch_alive_pos: 2 * n_sent int32.
- * n_alive (device, 1 int32) receives the number of surviving sentences.  Three launches on `stream`. */
+ * n_alive (device, 1 int32) receives the number of surviving sentences.  Three launches on `stream` (one up to 160 rows). */
 int tst_retire_compact(const tst_rows* cur, const tst_rows* nxt, const int32_t* sel_parent, const int32_t* sel_tok,
                        const float* sel_score, const int32_t* sel_fin, const int32_t* sel_nemit, const float* lp,
                        int64_t n_sent, int64_t k, int64_t step, int64_t T, int32_t eos, int last_step, int top_ends,
                        int32_t* out_tok, int32_t* out_len, float* out_score, int32_t* scratch_alive_pos,
                        int32_t* row_parent, int32_t* n_alive, void* stream);
+
+/* tst_greedy_select followed by tst_retire_compact with k = 1 (top_ends does not apply), same arguments and results; up to
+ * 160 sentences the two are ONE launch of one workgroup (tst_retire_compact alone also takes that route up to 160 rows). */
+int tst_greedy_retire_compact(const int32_t* argmax_tok, const tst_rows* cur, const tst_rows* nxt, int32_t* sel_parent,
+                              int32_t* sel_tok, float* sel_score, int32_t* sel_fin, int32_t* sel_nemit, const float* lp,
+                              int64_t n_sent, int64_t step, int64_t T, int32_t eos, int last_step, int32_t* out_tok,
+                              int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent,
+                              int32_t* n_alive, void* stream);
 
 /* One decode step of a pre-norm transformer decoder stack, launched from native code: the sequence of
  * entry points above that evaluates the model called at /root/reference/src/inference.py:132 for ONE new position

@@ -111,6 +111,8 @@ _PROTOS = {
     'tst_gru_reorder_run': ([ctypes.POINTER(TstGruStep), c_vp, c_i64, c_vp], c_int),
     'tst_select_step_run': ([ctypes.POINTER(TstSelectStep), ctypes.POINTER(TstRows), ctypes.POINTER(TstRows), c_i64, c_i64, c_i64,
                              ctypes.c_uint32, c_int, c_vp], c_int),
+    'tst_greedy_retire_compact': ([c_vp, ctypes.POINTER(TstRows), ctypes.POINTER(TstRows), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                   c_i64, c_i64, c_i32, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_int),
     'tst_retire_compact': ([ctypes.POINTER(TstRows), ctypes.POINTER(TstRows), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
                             c_i64, c_i64, c_i64, c_i32, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_int),
 }

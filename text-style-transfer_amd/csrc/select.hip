@@ -448,6 +448,114 @@ __global__ __launch_bounds__(256) void gather_state_kernel(tst_rows cur, tst_row
     }
 }
 
+// Small batches: greedy selection (optional), retirement, the prefix sum and the gather in ONE workgroup of 1024
+// threads (at most 1024 sentences and 1024 rows), the same arithmetic as the four kernels above, phase by phase.
+template <bool GREEDY>
+__global__ __launch_bounds__(1024) void tail_small_kernel(tst_rows cur, tst_rows nxt, const int32_t* __restrict__ am, int32_t* parent,
+                                                          int32_t* tok, float* score, int32_t* fin, int32_t* nemit,
+                                                          const float* __restrict__ lp, int n_sent, int k, int step, int T,
+                                                          int32_t eos, int last_step, int top_ends, int32_t* out_tok,
+                                                          int32_t* out_len, float* out_score, int32_t* row_parent,
+                                                          int32_t* n_alive) {
+    __shared__ int alive_s[1024], pos_s[1024], wsum[16];
+    const int t = threadIdx.x;
+    const int n_rows = n_sent * k;
+    if (GREEDY) {   // greedy_select_kernel (k == 1)
+        if (t < n_rows) {
+            const int32_t tk = am[t];
+            parent[t] = t;
+            tok[t] = tk;
+            score[t] = 0.0f;
+            fin[t] = tk == eos ? 1 : 0;
+            nemit[t] = cur.nemit[t] + 1;
+        }
+        __syncthreads();
+    }
+    int al = 0;
+    if (t < n_sent) {   // finish_kernel
+        const int base = t * k;
+        bool all_fin = true;
+        for (int j = 0; j < k; ++j) all_fin = all_fin && fin[base + j] != 0;
+        const bool done = all_fin || last_step != 0 || (top_ends != 0 && fin[base] != 0);
+        al = done ? 0 : 1;
+        if (done) {
+            int best = 0;
+            float br = score[base] / lp[nemit[base]];
+            for (int j = 1; j < k; ++j) {
+                const float rj = score[base + j] / lp[nemit[base + j]];
+                if (rj > br) { br = rj; best = j; }
+            }
+            const int sel = base + best;
+            const int64_t p = parent[sel];
+            const int64_t s = cur.sent[p];
+            const int plen = 1 + cur.nemit[p] - cur.fin[p];
+            const int olen = 1 + nemit[sel] - fin[sel];
+            for (int i = 0; i < plen; ++i) out_tok[s * (T + 1) + i] = cur.hist[p * (T + 1) + i];
+            if (olen > plen) out_tok[s * (T + 1) + plen] = tok[sel];
+            out_len[s] = olen;
+            out_score[s] = score[sel];
+        }
+    }
+    // scan_alive_kernel with one sentence per thread
+    int inc = al;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        if ((t & 63) >= off) inc += o;
+    }
+    if ((t & 63) == 63) wsum[t >> 6] = inc;
+    __syncthreads();
+    int wbase = 0;
+    for (int q = 0; q < (t >> 6); ++q) wbase += wsum[q];
+    alive_s[t] = al;
+    pos_s[t] = wbase + inc - al;
+    if (t == 1023) *n_alive = wbase + inc;
+    __syncthreads();
+    // gather_state_kernel: per-slot scalars by the slot's thread, then the history and ancestor rows element by element
+    // over the whole workgroup (every load independent of the others)
+    __shared__ int dst_s[1024], src_s[1024], plen_s[1024];
+    {
+        int dsti = -1, srci = 0, pl = 0;
+        if (t < n_rows) {
+            const int slot = t;
+            const int a = slot / k;
+            if (alive_s[a]) {
+                const int j = slot - a * k;
+                const int64_t dst = (int64_t)pos_s[a] * k + j;
+                const int64_t p = parent[slot];
+                const int plen = 1 + cur.nemit[p] - cur.fin[p];
+                const int nlen = 1 + nemit[slot] - fin[slot];
+                if (nlen > plen) nxt.hist[dst * (T + 1) + plen] = tok[slot];
+                if (cur.anc != nullptr && step < T) nxt.anc[dst * T + step] = (int32_t)p;
+                nxt.sent[dst] = cur.sent[p];
+                nxt.tok[dst] = tok[slot];
+                nxt.score[dst] = score[slot];
+                nxt.fin[dst] = fin[slot];
+                nxt.nemit[dst] = nemit[slot];
+                row_parent[dst] = (int32_t)p;
+                dsti = (int)dst; srci = (int)p; pl = plen;
+            }
+        }
+        dst_s[t] = dsti; src_s[t] = srci; plen_s[t] = pl;
+    }
+    __syncthreads();
+    const int W = T + 1;
+    for (int idx = t; idx < n_rows * W; idx += 1024) {
+        const int slot = idx / W, i = idx - slot * W;
+        const int dst = dst_s[slot];
+        if (dst >= 0 && i < plen_s[slot]) nxt.hist[(int64_t)dst * W + i] = cur.hist[(int64_t)src_s[slot] * W + i];
+    }
+    if (cur.anc != nullptr && step > 0) {
+        for (int idx = t; idx < n_rows * step; idx += 1024) {
+            const int slot = idx / step, i = idx - slot * step;
+            const int dst = dst_s[slot];
+            if (dst >= 0) nxt.anc[(int64_t)dst * T + i] = cur.anc[(int64_t)src_s[slot] * T + i];
+        }
+    }
+}
+
+constexpr int64_t SMALL_TAIL_ROWS = 160;
+
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
 template <typename T>
@@ -571,13 +679,19 @@ extern "C" int tst_retire_compact(const tst_rows* cur, const tst_rows* nxt, cons
                                   int64_t T, int32_t eos, int last_step, int top_ends, int32_t* out_tok,
                                   int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent,
                                   int32_t* n_alive, void* stream) {
-    (void)eos;
     TST_REQUIRE(rows_ok(cur, false) && rows_ok(nxt, cur && cur->anc) && sel_parent && sel_tok && sel_score && sel_fin &&
                     sel_nemit && lp && out_tok && out_len && out_score && scratch_alive_pos && row_parent && n_alive,
                 TST_ERR_ARG, "tst_retire_compact: null pointer");
     TST_REQUIRE(n_sent >= 0 && k >= 1 && k <= 8 && step >= 0 && step < T && n_sent * k < (1ll << 31), TST_ERR_ARG,
                 "tst_retire_compact: bad sizes (need 0 <= step < T, 1 <= k <= 8)");
     hipStream_t st = (hipStream_t)stream;
+    if (n_sent * k <= SMALL_TAIL_ROWS) {   // one workgroup does all three steps
+        hipLaunchKernelGGL(tail_small_kernel<false>, dim3(1), dim3(1024), 0, st, *cur, *nxt, nullptr, const_cast<int32_t*>(sel_parent),
+                           const_cast<int32_t*>(sel_tok), const_cast<float*>(sel_score), const_cast<int32_t*>(sel_fin),
+                           const_cast<int32_t*>(sel_nemit), lp, (int)n_sent, (int)k, (int)step, (int)T, eos, last_step, top_ends,
+                           out_tok, out_len, out_score, row_parent, n_alive);
+        return tst_after_launch("tst_retire_compact");
+    }
     int32_t* alive = scratch_alive_pos;
     int32_t* pos = scratch_alive_pos + n_sent;
     if (n_sent > 0) {
@@ -592,4 +706,25 @@ extern "C" int tst_retire_compact(const tst_rows* cur, const tst_rows* nxt, cons
                            row_parent);
     }
     return tst_after_launch("tst_retire_compact");
+}
+
+extern "C" int tst_greedy_retire_compact(const int32_t* argmax_tok, const tst_rows* cur, const tst_rows* nxt, int32_t* sel_parent,
+                                         int32_t* sel_tok, float* sel_score, int32_t* sel_fin, int32_t* sel_nemit, const float* lp,
+                                         int64_t n_sent, int64_t step, int64_t T, int32_t eos, int last_step, int32_t* out_tok,
+                                         int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent,
+                                         int32_t* n_alive, void* stream) {
+    if (n_sent > SMALL_TAIL_ROWS || n_sent <= 0) {
+        const int rc = tst_greedy_select(argmax_tok, n_sent, eos, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, cur, stream);
+        if (rc != TST_OK) return rc;
+        return tst_retire_compact(cur, nxt, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, lp, n_sent, 1, step, T, eos, last_step, 0,
+                                  out_tok, out_len, out_score, scratch_alive_pos, row_parent, n_alive, stream);
+    }
+    TST_REQUIRE(argmax_tok && rows_ok(cur, false) && rows_ok(nxt, cur && cur->anc) && sel_parent && sel_tok && sel_score && sel_fin &&
+                    sel_nemit && lp && out_tok && out_len && out_score && row_parent && n_alive,
+                TST_ERR_ARG, "tst_greedy_retire_compact: null pointer");
+    TST_REQUIRE(step >= 0 && step < T, TST_ERR_ARG, "tst_greedy_retire_compact: bad sizes (need 0 <= step < T)");
+    hipLaunchKernelGGL(tail_small_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, *cur, *nxt, argmax_tok, sel_parent, sel_tok,
+                       sel_score, sel_fin, sel_nemit, lp, (int)n_sent, 1, (int)step, (int)T, eos, last_step, 0, out_tok, out_len,
+                       out_score, row_parent, n_alive);
+    return tst_after_launch("tst_greedy_retire_compact");
 }
