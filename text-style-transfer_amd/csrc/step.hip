@@ -1,6 +1,6 @@
-// Host-side executor of one transformer decode step: the launch sequence of a whole model step issued from
-// native code in one call, so that small batches are not bound by per-launch interpreter overhead.
-// Contains no kernels; every launch goes through the single-kernel entry points of this library.
+// Host-side executors of a decode step: the launch sequence of a whole model step (transformer stack, GRU stack) and of
+// the selection / retirement tail, each issued from native code in one call, so that small batches are not bound by
+// per-launch interpreter overhead.  Contains no kernels; every launch goes through the entry points of this library.
 #include "tst_common.h"
 
 namespace {
