@@ -17,7 +17,9 @@ Two things live here:
       attributes ``.embed`` and ``.gru`` (``/root/reference/src/trainers/cyclegan_trainer.py:64``,
       ``/root/reference/src/prod/style_model.py:39,64-69``)
     - ``RNNLM``: ``lm(z, x, return_z=True) -> (logits, z')``
-      (``/root/reference/src/prod/dialog_model.py:97-120``)
+      (``/root/reference/src/prod/dialog_model.py:97-120``); ``ConditionalLM`` with ``style=`` (``:52,99-100``)
+    - ``RNNEncoder``, ``Generator`` (``/root/reference/src/trainers/cyclegan_trainer.py:63,337-348``), ``FFN``
+      (``/root/reference/src/prod/style_model.py:40,67``), ``TransformerLM`` (``/root/reference/src/trainers/lm_trainer.py:54,72-74``)
   Parity of this arithmetic against the absent submodule is unpinned.
 
 * ``RefInferenceState`` / ``ref_simple_inference``: a restatement of the decode loop of
