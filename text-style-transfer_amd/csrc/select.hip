@@ -27,7 +27,8 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
     argmax_step<1>(v, i);
 }
 
-// block-wide (256 threads) argmax; result valid in every thread. red_* are LDS arrays of 4.
+// block-wide argmax over NW waves (256 threads unless stated); result valid in every thread. red_* are LDS arrays of NW.
+template <int NW = 4>
 __device__ __forceinline__ void block_argmax(float& v, int& i, float* red_v, int* red_i) {
     wave_argmax(v, i);
     const int w = threadIdx.x >> 6;
@@ -36,7 +37,7 @@ __device__ __forceinline__ void block_argmax(float& v, int& i, float* red_v, int
     __syncthreads();
     v = red_v[0]; i = red_i[0];
 #pragma unroll
-    for (int q = 1; q < 4; ++q)
+    for (int q = 1; q < NW; ++q)
         if (better(red_v[q], red_i[q], v, i)) { v = red_v[q]; i = red_i[q]; }
 }
 
@@ -70,24 +71,26 @@ __device__ __forceinline__ void load_chunk(const __bf16* xr, int c, int V, bool 
     for (int q = 0; q < 8; ++q) o[q] = 8 * c + q < V ? (float)xr[8 * c + q] : -INFINITY;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void argmax_rows_kernel(const T* __restrict__ x, int64_t ld, int V,
-                                                          int32_t* __restrict__ tok, int vec_ok) {
+// One workgroup of BLOCK threads per row.  With few rows (one workgroup per CU or less) 1024 threads put four times as
+// many loads in flight per row; the first maximal index is the same whatever the split.
+template <typename T, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void argmax_rows_kernel(const T* __restrict__ x, int64_t ld, int V,
+                                                            int32_t* __restrict__ tok, int vec_ok) {
     constexpr int EPC = Elem<T>::EPC;
-    __shared__ float red_v[4];
-    __shared__ int red_i[4];
+    __shared__ float red_v[BLOCK / 64];
+    __shared__ int red_i[BLOCK / 64];
     const T* xr = x + (int64_t)blockIdx.x * ld;
     const int nch = (V + EPC - 1) / EPC;
     float bv = -INFINITY;
     int bi = INT_MAX;
-    for (int c = threadIdx.x; c < nch; c += 256) {
+    for (int c = threadIdx.x; c < nch; c += BLOCK) {
         float e[EPC];
         load_chunk(xr, c, V, vec_ok != 0, e);
 #pragma unroll
         for (int q = 0; q < EPC; ++q)
             if (e[q] > bv) { bv = e[q]; bi = EPC * c + q; }
     }
-    block_argmax(bv, bi, red_v, red_i);
+    block_argmax<BLOCK / 64>(bv, bi, red_v, red_i);
     if (threadIdx.x == 0) tok[blockIdx.x] = bi == INT_MAX ? 0 : bi;
 }
 
@@ -596,8 +599,12 @@ int argmax_entry(const T* logits, int64_t ld, int64_t R, int64_t V, int32_t* tok
     TST_REQUIRE(logits && tok, TST_ERR_ARG, "%s: null pointer", name);
     TST_REQUIRE(R >= 0 && V > 0 && ld >= V && V < (1ll << 30) && R < (1ll << 31), TST_ERR_ARG, "%s: bad sizes", name);
     if (R == 0) return TST_OK;
-    hipLaunchKernelGGL(argmax_rows_kernel<T>, dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, ld, (int)V, tok,
-                       row_vec_ok(logits, ld));
+    if (R <= 512 && V >= 8192)
+        hipLaunchKernelGGL((argmax_rows_kernel<T, 1024>), dim3((unsigned)R), dim3(1024), 0, (hipStream_t)stream, logits, ld, (int)V, tok,
+                           row_vec_ok(logits, ld));
+    else
+        hipLaunchKernelGGL((argmax_rows_kernel<T, 256>), dim3((unsigned)R), dim3(256), 0, (hipStream_t)stream, logits, ld, (int)V, tok,
+                           row_vec_ok(logits, ld));
     return tst_after_launch(name);
 }
 
