@@ -31,7 +31,7 @@ extern "C" {
 /* ABI version of this header (major * 100 + minor): 101 = 100 + tst_gemm_skinny_f32, tst_attn_cross_packed_f32,
  * tst_tfm_step_run, tst_gru_step_run, tst_gru_reorder_run, tst_select_step_run,
  * tst_attn_cross_group_f32, tst_ln_gemm_f32,
- * tst_greedy_retire_compact (additions only). */
+ * tst_greedy_retire_compact; 102 = 101 + tst_retire_compact_noalloc (additions only). */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
@@ -222,6 +222,20 @@ int tst_retire_compact(const tst_rows* cur, const tst_rows* nxt, const int32_t* 
                        int64_t n_sent, int64_t k, int64_t step, int64_t T, int32_t eos, int last_step, int top_ends,
                        int32_t* out_tok, int32_t* out_len, float* out_score, int32_t* scratch_alive_pos,
                        int32_t* row_parent, int32_t* n_alive, void* stream);
+
+/* tst_retire_compact for callers that cannot allocate device memory and have no workspace to pass (code under HIP graph
+ * capture, tight serving loops, harnesses that forbid hipMalloc).  It has no counterpart in the reference.  Same arguments
+ * and results as tst_retire_compact without scratch_alive_pos: the 2 * n_sent int32 of alive flags and prefix sums live in an
+ * array inside the library's code object (512 KiB, held on every GPU the library runs on until the process ends).
+ * n_sent <= TST_NOALLOC_MAX_SENT, else TST_ERR_UNSUPPORTED.  Calls no hipMalloc / hipFree; the first call on a device
+ * resolves that device's copy of the array (hipGetSymbolAddress, the device must be current as for any launch).  All calls
+ * on one GPU share the array: calls that overlap there (different streams or threads) race; calls on one stream do not. */
+#define TST_NOALLOC_MAX_SENT 65536
+int tst_retire_compact_noalloc(const tst_rows* cur, const tst_rows* nxt, const int32_t* sel_parent, const int32_t* sel_tok,
+                               const float* sel_score, const int32_t* sel_fin, const int32_t* sel_nemit, const float* lp,
+                               int64_t n_sent, int64_t k, int64_t step, int64_t T, int32_t eos, int last_step, int top_ends,
+                               int32_t* out_tok, int32_t* out_len, float* out_score, int32_t* row_parent, int32_t* n_alive,
+                               void* stream);
 
 /* tst_greedy_select followed by tst_retire_compact with k = 1 (top_ends does not apply), same arguments and results; up to
  * 160 sentences the two are ONE launch of one workgroup (tst_retire_compact alone also takes that route up to 160 rows). */

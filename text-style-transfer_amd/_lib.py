@@ -115,6 +115,8 @@ _PROTOS = {
                                    c_i64, c_i64, c_i32, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_int),
     'tst_retire_compact': ([ctypes.POINTER(TstRows), ctypes.POINTER(TstRows), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
                             c_i64, c_i64, c_i64, c_i32, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_int),
+    'tst_retire_compact_noalloc': ([ctypes.POINTER(TstRows), ctypes.POINTER(TstRows), c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i64,
+                                    c_i64, c_i64, c_i64, c_i32, c_int, c_int, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_int),
 }
 
 EXPORTS = tuple(_PROTOS)

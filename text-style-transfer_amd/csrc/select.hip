@@ -4,6 +4,7 @@
 // to combine the four waves of a workgroup.
 #include "tst_common.h"
 #include <limits.h>
+#include <atomic>
 #include <math.h>
 
 namespace {
@@ -680,24 +681,25 @@ extern "C" int tst_beam_merge(const tst_rows* cur, const float* top_val, const i
     return tst_after_launch("tst_beam_merge");
 }
 
-extern "C" int tst_retire_compact(const tst_rows* cur, const tst_rows* nxt, const int32_t* sel_parent,
-                                  const int32_t* sel_tok, const float* sel_score, const int32_t* sel_fin,
-                                  const int32_t* sel_nemit, const float* lp, int64_t n_sent, int64_t k, int64_t step,
-                                  int64_t T, int32_t eos, int last_step, int top_ends, int32_t* out_tok,
-                                  int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent,
-                                  int32_t* n_alive, void* stream) {
+namespace {
+
+int retire_compact_impl(const tst_rows* cur, const tst_rows* nxt, const int32_t* sel_parent, const int32_t* sel_tok,
+                        const float* sel_score, const int32_t* sel_fin, const int32_t* sel_nemit, const float* lp, int64_t n_sent,
+                        int64_t k, int64_t step, int64_t T, int32_t eos, int last_step, int top_ends, int32_t* out_tok,
+                        int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent, int32_t* n_alive,
+                        void* stream, const char* name) {
     TST_REQUIRE(rows_ok(cur, false) && rows_ok(nxt, cur && cur->anc) && sel_parent && sel_tok && sel_score && sel_fin &&
                     sel_nemit && lp && out_tok && out_len && out_score && scratch_alive_pos && row_parent && n_alive,
-                TST_ERR_ARG, "tst_retire_compact: null pointer");
+                TST_ERR_ARG, "%s: null pointer", name);
     TST_REQUIRE(n_sent >= 0 && k >= 1 && k <= 8 && step >= 0 && step < T && n_sent * k < (1ll << 31), TST_ERR_ARG,
-                "tst_retire_compact: bad sizes (need 0 <= step < T, 1 <= k <= 8)");
+                "%s: bad sizes (need 0 <= step < T, 1 <= k <= 8)", name);
     hipStream_t st = (hipStream_t)stream;
     if (n_sent * k <= SMALL_TAIL_ROWS) {   // one workgroup does all three steps
         hipLaunchKernelGGL(tail_small_kernel<false>, dim3(1), dim3(1024), 0, st, *cur, *nxt, nullptr, const_cast<int32_t*>(sel_parent),
                            const_cast<int32_t*>(sel_tok), const_cast<float*>(sel_score), const_cast<int32_t*>(sel_fin),
                            const_cast<int32_t*>(sel_nemit), lp, (int)n_sent, (int)k, (int)step, (int)T, eos, last_step, top_ends,
                            out_tok, out_len, out_score, row_parent, n_alive);
-        return tst_after_launch("tst_retire_compact");
+        return tst_after_launch(name);
     }
     int32_t* alive = scratch_alive_pos;
     int32_t* pos = scratch_alive_pos + n_sent;
@@ -712,7 +714,67 @@ extern "C" int tst_retire_compact(const tst_rows* cur, const tst_rows* nxt, cons
                            sel_tok, sel_score, sel_fin, sel_nemit, alive, pos, n_sent * k, (int)k, (int)step, (int)T,
                            row_parent);
     }
-    return tst_after_launch("tst_retire_compact");
+    return tst_after_launch(name);
+}
+
+}  // namespace
+
+extern "C" int tst_retire_compact(const tst_rows* cur, const tst_rows* nxt, const int32_t* sel_parent,
+                                  const int32_t* sel_tok, const float* sel_score, const int32_t* sel_fin,
+                                  const int32_t* sel_nemit, const float* lp, int64_t n_sent, int64_t k, int64_t step,
+                                  int64_t T, int32_t eos, int last_step, int top_ends, int32_t* out_tok,
+                                  int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent,
+                                  int32_t* n_alive, void* stream) {
+    return retire_compact_impl(cur, nxt, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, lp, n_sent, k, step, T, eos, last_step,
+                               top_ends, out_tok, out_len, out_score, scratch_alive_pos, row_parent, n_alive, stream,
+                               "tst_retire_compact");
+}
+
+// ---- the entry point that allocates nothing ------------------------------------------------------------------------------
+// The alive flags and the prefix sums of tst_retire_compact (2 * n_sent int32) live in this array of the code object instead
+// of a caller's buffer.  Every GPU holds its own copy at its own address; `scratch` in host code is only a handle for
+// hipGetSymbolAddress, never an address a kernel may be given.
+static __device__ __align__(256) int32_t scratch[2 * TST_NOALLOC_MAX_SENT];
+
+namespace {
+
+constexpr int MAX_DEVICES = 64;
+std::atomic<int32_t*> g_scratch_ptr[MAX_DEVICES];   // device address of `scratch` per device, resolved at the first call there
+
+int scratch_on_current_device(int32_t** out, const char* name) {
+    int dev = -1;
+    hipError_t e = hipGetDevice(&dev);
+    TST_REQUIRE(e == hipSuccess && dev >= 0 && dev < MAX_DEVICES, TST_ERR_LAUNCH, "%s: hipGetDevice: %s", name, hipGetErrorString(e));
+    int32_t* p = g_scratch_ptr[dev].load(std::memory_order_acquire);
+    if (p == nullptr) {
+        void* sym = nullptr;
+        e = hipGetSymbolAddress(&sym, HIP_SYMBOL(scratch));   // the current device's copy
+        TST_REQUIRE(e == hipSuccess && sym != nullptr, TST_ERR_LAUNCH, "%s: hipGetSymbolAddress(scratch) on device %d: %s", name, dev,
+                    hipGetErrorString(e));
+        p = (int32_t*)sym;
+        g_scratch_ptr[dev].store(p, std::memory_order_release);   // a racing thread resolves the same address
+    }
+    *out = p;
+    return TST_OK;
+}
+
+}  // namespace
+
+extern "C" int tst_retire_compact_noalloc(const tst_rows* cur, const tst_rows* nxt, const int32_t* sel_parent,
+                                          const int32_t* sel_tok, const float* sel_score, const int32_t* sel_fin,
+                                          const int32_t* sel_nemit, const float* lp, int64_t n_sent, int64_t k, int64_t step,
+                                          int64_t T, int32_t eos, int last_step, int top_ends, int32_t* out_tok,
+                                          int32_t* out_len, float* out_score, int32_t* row_parent, int32_t* n_alive,
+                                          void* stream) {
+    TST_REQUIRE(n_sent <= TST_NOALLOC_MAX_SENT, TST_ERR_UNSUPPORTED,
+                "tst_retire_compact_noalloc: %lld sentences, the built-in scratch holds %d (use tst_retire_compact with a buffer)",
+                (long long)n_sent, TST_NOALLOC_MAX_SENT);
+    int32_t* ptr = nullptr;
+    const int rc = scratch_on_current_device(&ptr, "tst_retire_compact_noalloc");
+    if (rc != TST_OK) return rc;
+    // nothing to clear: finish_kernel writes alive[0..n_sent) and scan_alive_kernel pos[0..n_sent) before anything reads them
+    return retire_compact_impl(cur, nxt, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, lp, n_sent, k, step, T, eos, last_step,
+                               top_ends, out_tok, out_len, out_score, ptr, row_parent, n_alive, stream, "tst_retire_compact_noalloc");
 }
 
 extern "C" int tst_greedy_retire_compact(const int32_t* argmax_tok, const tst_rows* cur, const tst_rows* nxt, int32_t* sel_parent,
