@@ -59,13 +59,20 @@ def test_two_rank_sharded_decode_equals_single_process(tmp_path, n_sent, batch):
         assert torch.equal(tok, want_tok)
 
 
-def test_shard_plan_is_a_length_sorted_partition():
+def test_shard_plan_deals_the_length_sorted_sentences_round_robin():
     import importlib
     sys.path.insert(0, ROOT)
     shard = importlib.import_module('text-style-transfer_amd.shard')
     lens = torch.tensor([5, 3, 9, 3, 7, 1, 8])
     order, per = shard.shard_plan(lens, 3)
     assert per == 3 and sorted(order.tolist()) == list(range(7))
-    parts = [shard.my_shard(order, per, r) for r in range(3)]
-    assert [len(p) for p in parts] == [3, 3, 1]
-    assert lens[parts[0]].max() <= lens[parts[1]].min() and lens[parts[1]].max() <= lens[parts[2]].min()
+    parts = [shard.my_shard(order, 3, r) for r in range(3)]
+    assert [len(p) for p in parts] == [3, 2, 2]
+    assert sorted(torch.cat(parts).tolist()) == list(range(7))
+    for p in parts:   # every shard is sorted by length, and the shards interleave: similar length distributions
+        assert lens[p].tolist() == sorted(lens[p].tolist())
+    assert lens[parts[0]].tolist() == [1, 5, 9] and lens[parts[1]].tolist() == [3, 7] and lens[parts[2]].tolist() == [3, 8]
+    big = torch.randint(4, 41, (10001,), generator=torch.Generator().manual_seed(0))
+    order, per = shard.shard_plan(big, 8)
+    sums = [int(big[shard.my_shard(order, 8, r)].sum()) for r in range(8)]
+    assert max(sums) - min(sums) <= 40 * 2   # the ranks' total source lengths differ by less than two sentences

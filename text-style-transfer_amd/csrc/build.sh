@@ -1,15 +1,24 @@
 #!/bin/bash
 # Builds libtst_hip.so (gfx950) next to the Python package. No fast-math, no fp contraction: the kernels
-# rely on a fixed fp32 operation order.
+# rely on a fixed fp32 operation order.  A translation unit that fails to compile fails the build: its stale
+# object is removed first, and every compile job's status is checked.
 set -e
 cd "$(dirname "$0")"
 OUT=../libtst_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -ffp-contract=off -std=c++17 -Wall -Wno-unused-result"
-for f in capi gemm_f32 gemm_bf16 rowops attn select gumbel step; do
+UNITS="capi gemm_f32 gemm_bf16 rowops attn select gumbel step"
+pids=()
+for f in $UNITS; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ tst_common.h -nt $f.o ] || [ ../../include/tst_hip.h -nt $f.o ]; then
+    rm -f $f.o
     /opt/rocm/bin/hipcc $FLAGS -c $f.hip -o $f.o &
+    pids+=($!)
   fi
 done
-wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT capi.o gemm_f32.o gemm_bf16.o rowops.o attn.o select.o gumbel.o step.o
+for p in "${pids[@]}"; do
+  wait "$p" || { echo "build.sh: a compile job failed" >&2; exit 1; }
+done
+OBJS=""
+for f in $UNITS; do OBJS="$OBJS $f.o"; done
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT $OBJS
 echo "built $OUT"
