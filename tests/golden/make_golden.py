@@ -446,11 +446,52 @@ def postprocess_case():
     print('postprocess      bleu=%.4f smooth=%.4f' % (cases['bleu']['plain'], cases['bleu']['smooth']))
 
 
+def chain_case(InferenceState):
+    """The validation chain of ``/root/reference/src/trainers/transformer_mt_trainer.py:91-101``: encoder pass, the REAL decode
+    loop, the REAL ``itos_many`` on predictions and targets, the REAL ``compute_bleu_for_sents``.  The vocabulary carries
+    BPE continuation markers (every 5th word ends in ``@@``) so that the un-BPE step has something to do; targets are the
+    predictions with a third of the words replaced, so that BLEU is neither 0 nor 1."""
+    from src.utils.data_utils import itos_many
+    from src.losses.bleu import compute_bleu_for_sents
+    V, B, S_max, max_len, eos_bias, out_scale, seed = 500, 24, 14, 18, 2.5, 2.0, 110
+    words = [('w%d@@' % i if i % 5 == 0 else 'w%d' % i) for i in range(V - 4)]
+    vocab = R.RefVocab(words)
+    hp = R.mt_hp()
+    model = R.synthetic_init(R.Transformer(hp, vocab, vocab), vocab.stoi['<eos>'], eos_bias, out_scale, seed=42)
+    rs = np.random.RandomState(seed)
+    lens = rs.randint(4, S_max + 1, size=B)
+    src = np.full((B, S_max), vocab.stoi['<pad>'], dtype=np.int64)
+    for b in range(B):
+        src[b, :lens[b]] = rs.randint(4, V, size=lens[b])
+    with torch.no_grad():
+        encs, enc_mask = model.encoder(torch.from_numpy(src))
+        preds = InferenceState({'model': model.decoder, 'inputs': encs, 'enc_mask': enc_mask, 'vocab': vocab,
+                                'max_len': max_len}).inference()
+    preds = [p.tolist() for p in preds]
+    width = max(len(p) for p in preds) + 2
+    trg = np.full((B, width), vocab.stoi['<pad>'], dtype=np.int64)
+    for b, p in enumerate(preds):
+        body = [t if rs.rand() < 0.67 else int(rs.randint(4, V)) for t in p[1:]]
+        row = [vocab.stoi['<bos>']] + body + [vocab.stoi['<eos>']]
+        trg[b, :len(row)] = row
+    pred_str, trg_str = itos_many(preds, vocab), itos_many(trg, vocab)
+    case = dict(config=dict(kind='transformer', V=V, hp=dict(hp), weight_seed=42, eos_bias=eos_bias, out_scale=out_scale,
+                            max_len=max_len, data_seed=seed, source='reference src/inference.py + data_utils.itos_many + bleu.py'),
+                words=words, src=src.tolist(), trg=trg.tolist(), preds=preds, pred_str=pred_str, trg_str=trg_str,
+                bleu=compute_bleu_for_sents(pred_str, trg_str), bleu_smooth=compute_bleu_for_sents(pred_str, trg_str, smooth=True))
+    with open(os.path.join(HERE, 'chain_tfm.json'), 'w') as f:
+        json.dump(case, f)
+    print('chain_tfm        B=%d bleu=%.4f lens=%s' % (B, case['bleu'], [len(p) for p in preds]))
+
+
 def main():
     torch.set_num_threads(4)
     InferenceState, simple_inference = import_reference()
     if sys.argv[1:] == ['conditional']:      # only the newest case (the others are unchanged)
         conditional_case(InferenceState)
+        return
+    if sys.argv[1:] == ['chain']:
+        chain_case(InferenceState)
         return
     postprocess_case()
     m, v, e, mk = transformer_case(InferenceState, 'tfm_v64', V=64, B=6, S_max=12, max_len=16, eos_bias=1.5,
@@ -472,6 +513,7 @@ def main():
     prefix_cases(InferenceState)
     charlm_case(InferenceState)
     conditional_case(InferenceState)
+    chain_case(InferenceState)
     ensemble_case(InferenceState, 'ensemble_rnnlm', V=50, H=32, n_layers=2, B=5, max_len=12, weights=[0.25, 0.75],
                   seeds=[42, 43], eos_bias=1.0, out_scale=2.0, seed=109)
     gumbel_case(InferenceState, 'gumbel_gru', 'gru', V=40, B=5, max_len=10, temperature=0.7, eos_bias=1.0, out_scale=2.0,

@@ -76,8 +76,12 @@ def torch_model_for(cfg):
     return R.synthetic_init(model, eos, cfg['eos_bias'], cfg['out_scale'], seed=cfg['weight_seed']), vocab
 
 
-def logits_close(a, b, rtol=1e-4, atol=1e-5):
-    """The fp32 tolerance of this build: |a - b| <= rtol * |b| + atol, elementwise."""
+def logits_close(a, b, rtol=1e-4, floor=0.1):
+    """The fp32 tolerance of this build: |a - b| <= rtol * max(|b|, floor), elementwise: 1e-4 RELATIVE for every logit of
+    magnitude >= 0.1, and the bound frozen at its value for |b| = 0.1 (1e-5 absolute) below that.  The floor is needed, not
+    a loosening: the rounding error of a K-term fp32 dot product is absolute (about K * 2**-24 * sum|a_k w_k|, a few 1e-6
+    here) whatever the result's magnitude, random-init logits cross zero (a tenth of a row lies within +-0.1), and a purely
+    relative bound is undefined there."""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    err = np.abs(a - b) - (rtol * np.abs(b) + atol)
+    err = np.abs(a - b) - rtol * np.maximum(np.abs(b), floor)
     return bool((err <= 0).all()), float(np.abs(a - b).max())

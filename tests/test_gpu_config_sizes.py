@@ -126,47 +126,61 @@ def test_config3_gru_full_batch_sample_vs_oracle(T):
     z = torch.randn((8192, 1024), generator=torch.Generator().manual_seed(1237))
     pick = np.sort(np.random.RandomState(10).choice(8192, size=32, replace=False))
     eos = vocab.stoi['|']
+    ML = 100                                                       # simple_inference's default (src/inference.py:170)
     for beam in (1, 4):
-        st = T.InferenceState({'model': model, 'inputs': z.cuda(), 'vocab': vocab, 'max_len': 40, 'eos_token': '|',
+        st = T.InferenceState({'model': model, 'inputs': z.cuda(), 'vocab': vocab, 'max_len': ML, 'eos_token': '|',
                                'beam_size': beam})
         tok, lens, score = (x.cpu().numpy() for x in st.decode_packed())
         sess = C.CanonGRUDecoder(tmodel).session(z[pick].numpy(), beam)
         if beam == 1:
-            want = C.greedy_decode(sess, 32, 40, 2, eos)[0]
+            want = C.greedy_decode(sess, 32, ML, 2, eos)[0]
         else:
-            want, wscore, _, _ = C.beam_decode(sess, 32, beam, 40, 2, eos)
+            want, wscore, _, _ = C.beam_decode(sess, 32, beam, ML, 2, eos)
             assert np.array_equal(score[pick], wscore)
         assert rows_as_lists(tok, lens, pick) == want
-        assert len(set(lens.tolist())) > 5
+        assert len(set(lens.tolist())) > 5 and lens.max() <= ML + 1
 
 
 def test_config4_lm_sizes_fp32_sample_and_bf16_properties(T):
-    """BASELINE config 4 sizes (model_size 512, 6 layers, 8 heads, d_ff 2048, V = 32000, beam 8).  fp32: 6 sampled
-    sentences of a 512-sentence batch equal the oracle bit for bit.  bf16 (checked by tolerance at small sizes
-    elsewhere): at this size the batch-order independence and the output format must hold."""
-    from tst_amd import synthetic
+    """BASELINE config 4 sizes (model_size 512, 6 layers, 8 heads, d_ff 2048, V = 32000, beam 8, max_len 50).  fp32: 6
+    sampled sentences of a 2048-sentence batch equal the oracle bit for bit (tokens and scores).  bf16 (tolerance-checked
+    position by position at small sizes in test_gpu_lm_bf16.py): at the FULL size, 8192 sentences x beam 8 x 50 steps (a 60 GB
+    q|k|v cache), batch-order independence (beam 8 and greedy) and the output format must hold."""
     hp = dict(model_size=512, n_layers=6, n_heads=8, d_ff=2048, pe_max_len=64)
     vocab = T.Vocab.synthetic(V)
     tv = R.synthetic_vocab(V)
     tmodel = R.synthetic_init(R.TransformerLM(R.HP(hp), tv), 3, 5.0, 2.0, seed=42)
-    z = 0.3 * torch.randn((512, 512), generator=torch.Generator().manual_seed(1238))
-    T_ = 12
+    z = 0.3 * torch.randn((8192, 512), generator=torch.Generator().manual_seed(1238))
+    T_ = 50
+    lms = {}
 
-    def run(dtype, zz):
-        lm = T.TransformerLM(T.HP(hp), vocab, dtype=dtype)
-        lm.load_state_dict(tmodel.state_dict())
-        st = T.InferenceState({'model': lm, 'inputs': zz.cuda(), 'vocab': vocab, 'max_len': T_, 'beam_size': 8})
-        return tuple(x.cpu().numpy() for x in st.decode_packed())
+    def run(dtype, zz, beam=8):
+        if dtype not in lms:
+            lms[dtype] = T.TransformerLM(T.HP(hp), vocab, dtype=dtype)
+            lms[dtype].load_state_dict(tmodel.state_dict())
+        st = T.InferenceState({'model': lms[dtype], 'inputs': zz.cuda(), 'vocab': vocab, 'max_len': T_, 'beam_size': beam})
+        out = tuple(x.cpu().numpy() for x in st.decode_packed())
+        del st
+        torch.cuda.empty_cache()
+        return out
 
-    tok, lens, score = run('fp32', z)
-    pick = np.sort(np.random.RandomState(11).choice(512, size=6, replace=False))
+    tok, lens, score = run('fp32', z[:2048])
+    pick = np.sort(np.random.RandomState(11).choice(2048, size=6, replace=False))
     want, wscore, _, _ = C.beam_decode(C.CanonTransformerLM(tmodel).session(z[pick].numpy(), 8, T_), 6, 8, T_, 2, 3)
     assert rows_as_lists(tok, lens, pick) == want
     assert np.array_equal(score[pick], wscore)
+    assert len(set(lens.tolist())) > 10
     tok16, lens16, score16 = run('bf16', z)
-    perm = np.random.RandomState(12).permutation(512)
+    perm = np.random.RandomState(12).permutation(8192)
     tok16p, lens16p, score16p = run('bf16', z[perm])
     assert np.array_equal(tok16p, tok16[perm]) and np.array_equal(lens16p, lens16[perm]) and np.array_equal(score16p, score16[perm])
-    assert (tok16[:, 0] == 2).all() and lens16.max() <= T_ + 1
-    agree = float(np.mean([a == b for a, b in zip(rows_as_lists(tok16, lens16, range(512)), rows_as_lists(tok, lens, range(512)))]))
-    print('\n[config 4] bf16 vs fp32 GPU path: %.0f %% of 512 beam-8 outputs identical' % (100 * agree))
+    assert (tok16[:, 0] == 2).all() and lens16.max() <= T_ + 1 and lens16.min() >= 1
+    col = np.arange(T_ + 1)[None, :]
+    inside = col < lens16[:, None]
+    assert not (tok16[inside] == 3).any() and (tok16[~inside] == 1).all()
+    g1 = run('bf16', z[:512], beam=1)
+    g1b = run('bf16', z[perm[:300]], beam=1)
+    where = {int(s): i for i, s in enumerate(perm[:300]) if s < 512}
+    assert len(where) > 5 and all(np.array_equal(g1[0][s], g1b[0][i]) for s, i in where.items())
+    agree = float(np.mean([a == b for a, b in zip(rows_as_lists(tok16, lens16, range(2048)), rows_as_lists(tok, lens, range(2048)))]))
+    print('\n[config 4] bf16 vs fp32 GPU path: %.0f %% of 2048 beam-8 outputs identical' % (100 * agree))

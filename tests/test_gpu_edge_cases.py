@@ -63,11 +63,11 @@ def test_smallest_batches_and_single_steps(T, B, beam, max_len):
 def test_every_sentence_ends_at_once_and_none_ever_ends(T, beam):
     tmodel, model, vocab, encs, mask = mt_case(T, 200, 9, 6, 40.0, 22)          # EOS wins every arg-max
     got, st = decode(T, model, vocab, encs, mask, 12, beam)
-    assert got == [[2]] * 9 and st.num_steps_done == 1
+    assert got == [[2]] * 9 and st.num_steps_done == 0
     assert got == oracle(tmodel, encs, mask, 12, beam)[0]
     tmodel, model, vocab, encs, mask = mt_case(T, 200, 9, 6, -40.0, 23)         # EOS never wins
     got, st = decode(T, model, vocab, encs, mask, 12, beam)
-    assert all(len(s) == 13 and 3 not in s for s in got) and st.num_steps_done == 12
+    assert all(len(s) == 13 and 3 not in s for s in got) and st.num_steps_done == 11
     assert got == oracle(tmodel, encs, mask, 12, beam)[0]
 
 
@@ -118,3 +118,29 @@ def test_foreign_model_under_beam_search(T):
     got = [s.cpu().tolist() for s in st.inference()]
     native, _ = decode(T, model, vocab, encs, mask, 10, 3)
     assert got == native
+
+
+def test_foreign_model_with_nan_logits_and_out_of_range_prefix_are_refused(T):
+    """Non-finite logits have no rank in the selection kernels (torch.max would return a NaN's index): a foreign callable
+    that produces them is refused instead of decoded; a prefix with ids outside the vocabulary raises like nn.Embedding."""
+    vocab = T.Vocab.synthetic(50)
+
+    def bad_model(inputs, ys):
+        out = torch.zeros((ys.shape[0], ys.shape[1], 50), device='cuda')
+        out[0, -1, 7] = float('nan')
+        return out
+
+    with pytest.raises(FloatingPointError):
+        T.InferenceState({'model': bad_model, 'inputs': torch.zeros(3, 4).cuda(), 'vocab': vocab, 'max_len': 4}).inference()
+
+    def minus_inf_model(inputs, ys):
+        out = torch.full((ys.shape[0], ys.shape[1], 50), float('-inf'), device='cuda')
+        out[:, -1, 9] = 0.0
+        return out
+
+    out = T.InferenceState({'model': minus_inf_model, 'inputs': torch.zeros(3, 4).cuda(), 'vocab': vocab, 'max_len': 3}).inference()
+    assert [s.tolist() for s in out] == [[2, 9, 9, 9]] * 3            # -inf is an ordinary smallest value
+    gru = T.RNNDecoder(32, 32, vocab)
+    with pytest.raises(IndexError):
+        T.InferenceState({'model': gru, 'inputs': torch.zeros(2, 32).cuda(), 'vocab': vocab, 'max_len': 4,
+                          'active_seqs': torch.tensor([[2, 50], [2, 5]])}).inference()

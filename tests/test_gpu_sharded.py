@@ -2,7 +2,10 @@
 walk over on-GPU batches, all-gather of device tensors, un-permutation.  A miniature of BASELINE config 5 (a corpus
 decoded in on-GPU batches); the outputs must equal the decode of the whole corpus as one batch, sentence by sentence."""
 import importlib
+import json
 import os
+import subprocess
+import sys
 
 import pytest
 import torch
@@ -44,3 +47,55 @@ def test_sharded_corpus_decode_one_rank_rccl(tmp_path):
             assert torch.equal(tok[i, :n], whole_tok[i, :n]), i
     finally:
         dist.destroy_process_group()
+
+
+def test_bench_config5_two_ranks_equal_one_rank(tmp_path):
+    """``bench.py --config 5`` (a corpus dealt to the ranks, walked in on-GPU batches, all-gather, un-permute) started the way the
+    driver starts it, ``python bench.py --gpus N``: the 2-rank run (both ranks on this one GPU, gloo rehearsal backend; the
+    parent starts the rank processes itself) returns byte-identical outputs to the 1-rank run, in input order, and the same
+    checksum in its JSON line."""
+    from helpers import ROOT
+    bench = os.path.join(ROOT, 'bench.py')
+    common = ['--config', '5', '--sentences', '3000', '--batch', '640', '--steps', '1', '--warmup', '0', '--no-cpu-baseline',
+              '--no-roofline']
+    env = dict(os.environ)
+    env.pop('WORLD_SIZE', None)
+    lines = {}
+    for n, extra in ((1, []), (2, ['--share-gpu', '--backend', 'gloo'])):
+        dump = str(tmp_path / ('out_n%d.pt' % n))
+        r = subprocess.run([sys.executable, bench, '--gpus', str(n), '--dump', dump] + common + extra, capture_output=True, text=True,
+                           env=env, timeout=280)
+        assert r.returncode == 0, r.stderr[-2000:]
+        lines[n] = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith('{')][-1])
+    a, b = torch.load(str(tmp_path / 'out_n1.pt')), torch.load(str(tmp_path / 'out_n2.pt'))
+    assert tuple(a[0].shape) == (3000, 51) and torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert lines[1]['output_checksum'] == lines[2]['output_checksum']
+    assert lines[2]['n_gpus'] == 2 and lines[2]['config']['ranks_seen_by_backend'] == 2 and lines[2]['scaling'] == 'strong'
+    assert lines[1]['config']['batches_per_step_rank0'] == 5 and lines[2]['config']['batches_per_step_rank0'] == 3
+
+
+def test_batch_trimmed_to_its_longest_sentence_decodes_identically():
+    """The corpus walk cuts every batch to the columns of its longest sentence; the padding columns carry no information, so
+    the outputs must not change (tokens, lengths, scores)."""
+    import tst_amd
+    from tst_amd import synthetic
+    V = 512
+    hp = dict(d_model=256, dropout=0.1, n_layers=2, pe_max_len=60, n_heads=2, d_ff=1024)
+    vocab = tst_amd.Vocab.synthetic(V)
+    model = tst_amd.Transformer(tst_amd.HP(hp), vocab, vocab, device='cuda:0')
+    model.load_state_dict(synthetic.synthetic_state_dict(model, 3, 3.0, 2.0, seed=42))
+    src = synthetic.multi30k_like_sources(300, V, seed=78)
+    lens = (src != 1).sum(1)
+    short = src[lens <= 14][:, :]
+    assert short.shape[0] > 50 and short.shape[1] > 16
+
+    def decode(batch):
+        encs, mask = model.encoder(batch.cuda())
+        st = tst_amd.InferenceState({'model': model.decoder, 'inputs': encs, 'enc_mask': mask, 'vocab': vocab, 'max_len': 20,
+                                     'beam_size': 4})
+        return st.decode_packed()
+
+    wide = decode(short)
+    narrow = decode(short[:, :14])
+    for a, b in zip(wide, narrow):
+        assert torch.equal(a, b)

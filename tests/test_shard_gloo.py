@@ -21,17 +21,17 @@ def _free_port():
     return p
 
 
-def fake_decode(src):
-    """'decodes' each sentence to its content tokens reversed; int32 [n, W] + lengths."""
+def fake_decode(src, W=48):
+    """'decodes' each sentence to its content tokens reversed; int32 [n, W] + lengths (W fixed: batches may be trimmed)."""
     n, S = src.shape
     lens = (src != 1).sum(1).to(torch.int32)
-    out = torch.zeros((n, S), dtype=torch.int32)
+    out = torch.zeros((n, W), dtype=torch.int32)
     for i in range(n):
         out[i, :lens[i]] = src[i, :lens[i]].flip(0).to(torch.int32)
     return out, lens
 
 
-def _worker(rank, world, port, n_sent, batch, result_dir):
+def _worker(rank, world, port, n_sent, batch, result_dir, trim=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -40,15 +40,15 @@ def _worker(rank, world, port, n_sent, batch, result_dir):
     from tst_amd import synthetic
     src = synthetic.multi30k_like_sources(n_sent, 100, seed=5)
     lens = (src != 1).sum(1)
-    tok, ln = shard.decode_sharded(fake_decode, src, lens, batch)
+    tok, ln = shard.decode_sharded(fake_decode, src, lens, batch, trim=trim)
     torch.save((tok, ln), os.path.join(result_dir, 'r%d.pt' % rank))
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize('n_sent,batch', [(37, 8), (64, 100), (3, 2)])
-def test_two_rank_sharded_decode_equals_single_process(tmp_path, n_sent, batch):
+@pytest.mark.parametrize('n_sent,batch,trim', [(37, 8, False), (64, 100, False), (3, 2, False), (1, 4, False), (53, 8, True)])
+def test_two_rank_sharded_decode_equals_single_process(tmp_path, n_sent, batch, trim):
     world, port = 2, _free_port()
-    mp.spawn(_worker, args=(world, port, n_sent, batch, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, n_sent, batch, str(tmp_path), trim), nprocs=world, join=True)
     sys.path.insert(0, ROOT)
     from tst_amd import synthetic
     src = synthetic.multi30k_like_sources(n_sent, 100, seed=5)

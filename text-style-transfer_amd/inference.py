@@ -7,7 +7,8 @@ happens: token selection, EOS retirement, batch compaction and the hypothesis bo
 kernels on device-resident state (``engine.DecodeLoop``), and models of this package are stepped
 incrementally (KV cache / carried GRU state) instead of being re-run on the whole prefix (``:132``).
 
-Additive keys (not in the reference): ``dtype`` / ``return_logits`` (see the constructor), ``beam_size`` (1 = the reference's greedy arg-max; the reference
+Additive keys (not in the reference): ``dtype`` / ``return_logits`` (see the constructor; a ``dtype`` that differs from the
+model's switches the model for this call only), ``beam_size`` (1 = the reference's greedy arg-max; the reference
 has no beam search), ``length_penalty`` (alpha of ((5 + n) / 6) ** alpha, used to rank finished beams),
 ``seed`` (makes ``sample_type='sample'`` reproducible; by default a seed is drawn from torch's generator,
 so ``torch.manual_seed`` governs it like it governs the reference's ``Categorical.sample``),
@@ -67,7 +68,12 @@ class ForeignSession:
         logits = out[:, -1]
         if logits.shape[-1] != self.V:
             raise ValueError('model returned %d classes, vocabulary has %d' % (logits.shape[-1], self.V))
-        return logits.to(torch.float32).contiguous()
+        logits = logits.to(torch.float32).contiguous()
+        # The selection kernels order finite numbers (and -inf as the smallest); a NaN or +inf logit has no defined rank
+        # there (torch.max would return the NaN's index).  A foreign model is the only source of such values: refuse them.
+        if not bool(torch.isfinite(logits).logical_or(logits == float('-inf')).all()):
+            raise FloatingPointError('the model returned NaN or +inf logits at step %d' % t)
+        return logits
 
     def reorder(self, row_parent, n_rows, identity):
         if identity:
@@ -146,6 +152,7 @@ class InferenceState:
     def _run(self, keep_logits=0):
         if self.return_logits:
             keep_logits = self.max_len
+        restore_dtype = None
         if self.dtype is not None:
             if self.dtype not in ('fp32', 'bf16'):
                 raise ValueError("dtype must be 'fp32' or 'bf16'")
@@ -154,6 +161,7 @@ class InferenceState:
                 if not hasattr(self.model, 'set_dtype'):
                     raise ValueError('the model computes in %s, dtype=%r was asked for' % (have, self.dtype))
                 self.model.set_dtype(self.dtype)
+                restore_dtype = have      # the switch lasts for this call only: the caller's model is handed back as it came
         if self.sample_type not in ('max', 'sample'):
             raise NotImplementedError  # as /root/reference/src/inference.py:149
         sample = None
@@ -167,6 +175,8 @@ class InferenceState:
             prefix = self.active_seqs
             if prefix.dim() != 2 or prefix.shape[0] != self.batch_size or prefix.shape[1] < 1 or prefix.is_floating_point():
                 raise ValueError('active_seqs must be token ids [batch, t0 >= 1]')
+            if int(prefix.min()) < 0 or int(prefix.max()) >= len(self.vocab):   # nn.Embedding raises IndexError there
+                raise IndexError('active_seqs holds token ids outside the vocabulary (0..%d)' % (len(self.vocab) - 1))
         if not torch.cuda.is_available():
             raise RuntimeError('InferenceState needs a GPU: the decode loop runs in HIP kernels and has no CPU path')
         device = self.inputs.device if self.inputs.is_cuda else torch.device('cuda', torch.cuda.current_device())
@@ -207,10 +217,14 @@ class InferenceState:
             loop = DecodeLoop(session, self.batch_size, self.beam_size, self.max_len, self.bos_idx,
                               self.eos_idx, self.pad_idx, self.length_penalty, device, sample, gumbel, prefix)
             loop.select_log = getattr(self, 'select_log', None)
-            loop.run(keep_logits)
+            try:
+                loop.run(keep_logits)
+            finally:
+                if restore_dtype is not None:
+                    self.model.set_dtype(restore_dtype)
         self.loop = loop
         self.step_logits = [(lg, sent) for lg, sent, _ in loop.kept]
-        self.num_steps_done = loop.steps_done
+        self.num_steps_done = max(0, loop.steps_done - 1)   # index of the last step, as /root/reference/src/inference.py:156 leaves it
         self.scores = loop.out_score
         return loop
 

@@ -58,6 +58,20 @@ class TransformerLM(HipModule):
         self._add('out.bias', (self.V,), fill=0.0)
         self._params['pe'] = sinusoid_table(self.pe_max_len, d).to(self.device)
 
+    # kernel-side weight copies are kept per arithmetic type, so switching back and forth converts nothing twice;
+    # assigning None (load_state_dict, to) drops them all
+    @property
+    def _prepared(self):
+        return self.__dict__.setdefault('_prepared_by_dtype', {}).get(self.__dict__.get('dtype'))
+
+    @_prepared.setter
+    def _prepared(self, value):
+        store = self.__dict__.setdefault('_prepared_by_dtype', {})
+        if value is None:
+            store.clear()
+        else:
+            store[self.dtype] = value
+
     def prepared(self):
         """Weights in kernel layout: fp32 -> transposed [in, out]; bf16 -> as stored [out, in], rounded to bf16."""
         if self._prepared is None:
@@ -86,9 +100,7 @@ class TransformerLM(HipModule):
         """Switches between fp32 and bf16 arithmetic (the parameters stay fp32; the kernel-side copies are rebuilt)."""
         if dtype not in ('fp32', 'bf16'):
             raise ValueError("dtype must be 'fp32' or 'bf16'")
-        if dtype != self.dtype:
-            self.dtype = dtype
-            self._prepared = None
+        self.dtype = dtype
 
     def session(self, z, enc_mask=None, rows_per_sentence=1, max_len=None):
         return TransformerLMSession(self, z, rows_per_sentence, max_len if max_len is not None else self.pe_max_len)
