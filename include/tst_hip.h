@@ -31,7 +31,8 @@ extern "C" {
 /* ABI version of this header (major * 100 + minor): 101 = 100 + tst_gemm_skinny_f32, tst_attn_cross_packed_f32,
  * tst_tfm_step_run, tst_gru_step_run, tst_gru_reorder_run, tst_select_step_run,
  * tst_attn_cross_group_f32, tst_ln_gemm_f32,
- * tst_greedy_retire_compact; 102 = 101 + tst_retire_compact_noalloc (additions only). */
+ * tst_greedy_retire_compact; 102 = 101 + tst_retire_compact_noalloc;
+ * 103 = 102 + tst_gru_cell_fused_f32, tst_gru_cell_fused_ok, TST_STEP_FUSED_CELL (additions only). */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
@@ -134,6 +135,19 @@ int tst_attn_cross_step_bf16(const void* q, const void* kv, const uint8_t* mask,
  * replaces the elementwise part of nn.GRU.  h_out may alias h.  H % 4 == 0. */
 int tst_gru_cell_step_f32(const float* gi, const float* gh, const float* h, float* h_out, int64_t R, int64_t H,
                           void* stream);
+
+/* The whole GRU cell step as ONE kernel: h_out = cell(x Wih + bih, h Whh + bhh, h) with the gate pre-activations kept in
+ * matrix-core accumulators (six per element: i_r, i_z, i_n, h_r, h_z, h_n, each the k-ordered fma chain of
+ * tst_gemm_mfma_f32) and tst_gru_cell_step_f32's update applied in the epilogue; gi and gh [R][3H] are never stored.
+ * Results are bit-identical to the three-call form.  replaces nn.GRU's step of the decoder called at
+ * /root/reference/src/inference.py:132 (model: /root/reference/src/trainers/cyclegan_trainer.py:64).
+ * x [R][ldx >= E], h [R][ldh >= H], wih [E][ld_wih >= 3H], whh [H][ld_whh >= 3H] (nn.GRU weights transposed, columns
+ * r | z | n), bih / bhh [3H] or NULL, h_out [R][ldo >= H] must NOT overlap h.  Needs E % 16 == 0 and H % 64 == 0
+ * (tst_gru_cell_fused_ok tells; TST_ERR_UNSUPPORTED otherwise), leading dimensions multiples of 4, 16-byte aligned inputs. */
+int tst_gru_cell_fused_ok(int64_t E, int64_t H);
+int tst_gru_cell_fused_f32(const float* x, int64_t ldx, const float* h, int64_t ldh, const float* wih, int64_t ld_wih,
+                           const float* bih, const float* whh, int64_t ld_whh, const float* bhh, float* h_out, int64_t ldo,
+                           int64_t R, int64_t E, int64_t H, void* stream);
 
 /* dst[r][:] = src[idx[r]][:], rows of `width` floats (width % 4 == 0); carried GRU state on reorder. */
 int tst_gather_rows_f32(const float* src, const int32_t* idx, float* dst, int64_t R, int64_t width, void* stream);
@@ -295,6 +309,9 @@ typedef struct tst_tfm_step {
 #define TST_STEP_EMBED 1   /* x = emb[tok] * scale + pe[t] (+ z[sent]); without it x must hold the embeddings */
 #define TST_STEP_LAYERS 2  /* the layer stack and the final LayerNorm (into h) */
 #define TST_STEP_VOCAB 4   /* logits = h * wout + bout */
+#define TST_STEP_FUSED_CELL 8 /* tst_gru_step_run only: every layer's cell is ONE kernel (tst_gru_cell_fused_f32) that reads the
+                                 state from h and writes the new state to h_alt; the caller swaps h and h_alt of every layer
+                                 in its struct after the call (as after tst_gru_reorder_run).  Same results. */
 /* Runs the phases selected in `phases` for rows 0..R-1 at position t (0 <= t < n_pos): tok [R] token ids,
  * anc [R][anc_ld] cache rows of earlier positions, sent [R] sentence of each row.  Stops at the first failing
  * launch and returns its code.  A caller that times the vocabulary projection calls it twice (phases 3, then 4). */

@@ -278,3 +278,36 @@ def test_sample_rows_bit_exact(K, V, temp):
     tok = torch.empty(R, dtype=torch.int32, device='cuda')
     K.sample_rows(dev(x), R, V, temp, 1234, 7, dev(sent), tok)
     assert np.array_equal(tok.cpu().numpy(), C.sample_rows(x, temp, 1234, 7, sent))
+
+
+@pytest.mark.parametrize('R,E,H', [(300, 64, 128), (129, 1024, 1024), (1, 32, 64), (2048, 256, 192)])
+def test_gru_cell_fused_equals_three_call_form_and_oracle(K, R, E, H):
+    """One kernel (gate pre-activations in the accumulators) against x Wih, h Whh, gru_cell as three calls and against the
+    canonical oracle: bit for bit; rows beyond R untouched; strided x / h / h_out views."""
+    rs = np.random.RandomState(R + E + H)
+    x = rs.standard_normal((R, E)).astype(np.float32)
+    h = rs.standard_normal((R, H)).astype(np.float32)
+    wih = (rs.standard_normal((E, 3 * H)) / np.sqrt(E)).astype(np.float32)
+    whh = (rs.standard_normal((H, 3 * H)) / np.sqrt(H)).astype(np.float32)
+    bih, bhh = (0.1 * rs.standard_normal(3 * H)).astype(np.float32), (0.1 * rs.standard_normal(3 * H)).astype(np.float32)
+    want = C.gru_cell(C.gemm(x, wih, bih), C.gemm(h, whh, bhh), h)
+    xd, hd, wi, wh, bi, bh = (torch.from_numpy(a).cuda() for a in (x, h, wih, whh, bih, bhh))
+    out = torch.full((R + 2, H), 7.0, device='cuda')
+    K.gru_cell_fused(xd, hd, wi, bi, wh, bh, out, R)
+    assert np.array_equal(out[:R].cpu().numpy(), want) and (out[R:] == 7.0).all()
+    gi, gh = torch.empty((R, 3 * H), device='cuda'), torch.empty((R, 3 * H), device='cuda')
+    K.gemm(xd, wi, bi, gi, R)
+    K.gemm(hd, wh, bh, gh, R)
+    three = torch.empty((R, H), device='cuda')
+    K.gru_cell_step(gi, gh, hd, three, R)
+    assert torch.equal(out[:R], three)
+    # strided operands, no biases
+    xs = torch.zeros((R, E + 8), device='cuda'); xs[:, :E] = xd
+    hs = torch.zeros((R, H + 4), device='cuda'); hs[:, :H] = hd
+    outs = torch.zeros((R, H + 12), device='cuda')
+    K.gru_cell_fused(xs[:, :E], hs[:, :H], wi, None, wh, None, outs[:, :H], R)
+    assert np.array_equal(outs[:, :H].cpu().numpy(), C.gru_cell(C.gemm(x, wih), C.gemm(h, whh), h)) and (outs[:, H:] == 0).all()
+    from tst_amd import _lib
+    with pytest.raises(_lib.TstError, match='must not overlap'):
+        K.gru_cell_fused(xd, hd, wi, bi, wh, bh, hd, R)
+    assert not K.gru_cell_fused_ok(1024, 1000) and not K.gru_cell_fused_ok(1028, 1024) and K.gru_cell_fused_ok(1024, 1024)

@@ -72,7 +72,7 @@ class TstSelectStep(ctypes.Structure):
                 ('n_alive', c_vp)]
 
 
-STEP_EMBED, STEP_LAYERS, STEP_VOCAB = 1, 2, 4
+STEP_EMBED, STEP_LAYERS, STEP_VOCAB, STEP_FUSED_CELL = 1, 2, 4, 8
 
 _PROTOS = {
     'tst_version': ([], c_int),
@@ -88,6 +88,8 @@ _PROTOS = {
     'tst_attn_cross_packed_f32': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_attn_cross_group_f32': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_gru_cell_step_f32': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
+    'tst_gru_cell_fused_ok': ([c_i64, c_i64], c_int),
+    'tst_gru_cell_fused_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_gather_rows_f32': ([c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_argmax_rows_f32': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_vp], c_int),
     'tst_gumbel_softmax_f32': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp, c_i64, c_vp], c_int),

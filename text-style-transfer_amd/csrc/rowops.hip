@@ -88,13 +88,6 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
-__device__ __forceinline__ float gru_elem(float ir, float iz, float in, float hr, float hz, float hn, float h) {
-    const float rg = d_sigmoid(ir + hr);
-    const float zg = d_sigmoid(iz + hz);
-    const float ng = d_tanh(__builtin_fmaf(rg, hn, in));
-    return __builtin_fmaf(zg, h, (1.0f - zg) * ng);
-}
-
 // one thread per float4 of h
 __global__ __launch_bounds__(256) void gru_cell_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
                                                        const float* h, float* h_out, int64_t R, int H4) {

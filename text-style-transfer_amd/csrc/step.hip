@@ -112,14 +112,18 @@ extern "C" int tst_gru_step_run(const tst_gru_step* m, const int32_t* tok, const
     TST_REQUIRE(m != nullptr && m->layers != nullptr, TST_ERR_ARG, "tst_gru_step_run: null plan");
     TST_REQUIRE(m->n_layers >= 1 && m->E > 0 && m->H > 0 && m->V > 0, TST_ERR_ARG, "tst_gru_step_run: bad sizes");
     TST_REQUIRE(R >= 0 && R <= m->rows, TST_ERR_ARG, "tst_gru_step_run: %lld rows, buffers hold %lld", (long long)R, (long long)m->rows);
-    TST_REQUIRE((phases & ~7) == 0 && phases != 0, TST_ERR_ARG, "tst_gru_step_run: bad phases %d", phases);
-    TST_REQUIRE(m->x && m->gi && m->gh && m->logits, TST_ERR_ARG, "tst_gru_step_run: null work buffer");
+    TST_REQUIRE((phases & ~15) == 0 && (phases & 7) != 0, TST_ERR_ARG, "tst_gru_step_run: bad phases %d", phases);
+    const bool fused = (phases & TST_STEP_FUSED_CELL) != 0;
+    TST_REQUIRE(!fused || tst_gru_cell_fused_ok(m->E, m->H), TST_ERR_UNSUPPORTED,
+                "tst_gru_step_run: TST_STEP_FUSED_CELL needs E %% 16 == 0 and H %% 64 == 0");
+    TST_REQUIRE(m->x && m->logits && (fused || (m->gi && m->gh)), TST_ERR_ARG, "tst_gru_step_run: null work buffer");
     if (R == 0) return TST_OK;
     if (phases & TST_STEP_EMBED) {
         TST_REQUIRE(tok && m->emb, TST_ERR_ARG, "tst_gru_step_run: null embedding input");
         TST_TRY(tst_embed_posadd_f32(tok, m->emb, nullptr, nullptr, 1.0f, m->x, R, m->E, m->V, stream));
     }
     const tst_gru_layer& top = m->layers[m->n_layers - 1];
+    const float* top_h = top.h;   // the state the output projection reads
     if (phases & TST_STEP_LAYERS) {
         if (m->extra != nullptr) {
             TST_REQUIRE(sent != nullptr, TST_ERR_ARG, "tst_gru_step_run: extra without sent");
@@ -130,6 +134,14 @@ extern "C" int tst_gru_step_run(const tst_gru_step* m, const int32_t* tok, const
         for (int l = 0; l < m->n_layers; ++l) {
             const tst_gru_layer& L = m->layers[l];
             TST_REQUIRE(L.wih && L.whh && L.h, TST_ERR_ARG, "tst_gru_step_run: layer %d incomplete", l);
+            if (fused) {
+                TST_REQUIRE(L.h_alt != nullptr, TST_ERR_ARG, "tst_gru_step_run: layer %d has no h_alt", l);
+                TST_TRY(tst_gru_cell_fused_f32(x, in, L.h, m->H, L.wih, L.ld_wih, L.bih, L.whh, L.ld_whh, L.bhh, L.h_alt, m->H, R, in,
+                                               m->H, stream));
+                x = L.h_alt;
+                in = m->H;
+                continue;
+            }
             TST_TRY(tst_gemm_mfma_f32(x, in, L.wih, L.ld_wih, L.bih, nullptr, 0, m->gi, 3 * m->H, R, 3 * m->H, in, 0, stream));
             TST_TRY(tst_gemm_mfma_f32(L.h, m->H, L.whh, L.ld_whh, L.bhh, nullptr, 0, m->gh, 3 * m->H, R, 3 * m->H, m->H, 0, stream));
             TST_TRY(tst_gru_cell_step_f32(m->gi, m->gh, L.h, L.h, R, m->H, stream));
@@ -137,9 +149,10 @@ extern "C" int tst_gru_step_run(const tst_gru_step* m, const int32_t* tok, const
             in = m->H;
         }
     }
+    if (fused && (phases & TST_STEP_LAYERS)) top_h = top.h_alt;
     if (phases & TST_STEP_VOCAB) {
         TST_REQUIRE(m->wout != nullptr, TST_ERR_ARG, "tst_gru_step_run: null output projection");
-        TST_TRY(tst_gemm_mfma_f32(top.h, m->H, m->wout, m->ld_wout, m->bout, nullptr, 0, m->logits, m->ld_logits, R, m->V, m->H, 0,
+        TST_TRY(tst_gemm_mfma_f32(top_h, m->H, m->wout, m->ld_wout, m->bout, nullptr, 0, m->logits, m->ld_logits, R, m->V, m->H, 0,
                                   stream));
     }
     return TST_OK;

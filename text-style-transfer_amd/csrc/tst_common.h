@@ -147,3 +147,14 @@ __device__ __forceinline__ float d_tanh(float x) {
     float r = (1.0f - t) / (1.0f + t);
     return copysignf(r, x);
 }
+
+// GRU gate update of one element (PyTorch gate order): r = sigmoid(i_r + h_r), z = sigmoid(i_z + h_z),
+// n = tanh(i_n + r * h_n), h' = (1 - z) * n + z * h; the operation order is part of the canonical arithmetic.
+__device__ __forceinline__ float gru_elem(float ir, float iz, float in, float hr, float hz, float hn, float h) {
+    const float rg = d_sigmoid(ir + hr);
+    const float zg = d_sigmoid(iz + hz);
+    const float ng = d_tanh(__builtin_fmaf(rg, hn, in));
+    return __builtin_fmaf(zg, h, (1.0f - zg) * ng);
+}
+
+

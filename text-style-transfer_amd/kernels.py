@@ -7,7 +7,7 @@ Where a kernel exists for fp32 and bf16 storage the wrapper picks the entry poin
 import torch
 
 from . import _lib
-from ._lib import call, STEP_EMBED, STEP_LAYERS, STEP_VOCAB  # noqa: F401
+from ._lib import call, STEP_EMBED, STEP_LAYERS, STEP_VOCAB, STEP_FUSED_CELL  # noqa: F401
 
 
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
@@ -176,6 +176,22 @@ def gru_cell_step(gi, gh, h, h_out, n_rows):
     call('tst_gru_cell_step_f32', _p(gi), _p(gh), _p(h), _p(h_out), n_rows, H, _stream())
 
 
+def gru_cell_fused_ok(E, H):
+    return bool(_lib._dll.tst_gru_cell_fused_ok(E, H))
+
+
+def gru_cell_fused(x, h, wih, bih, whh, bhh, h_out, n_rows):
+    """h_out[:n_rows] = GRU cell(x @ wih + bih, h @ whh + bhh, h) as one kernel; ``wih`` [E, 3H], ``whh`` [H, 3H] (transposed
+    nn.GRU weights); ``h_out`` must not overlap ``h``."""
+    for t, nm in ((x, 'x'), (h, 'h'), (wih, 'wih'), (whh, 'whh'), (h_out, 'h_out'), (bih, 'bih'), (bhh, 'bhh')):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1):
+            raise ValueError('%s must be an fp32 GPU tensor with unit inner stride' % nm)
+    E, H = wih.shape[0], whh.shape[0]
+    assert x.shape[1] == E and h.shape[1] == H and h_out.shape[1] == H and min(x.shape[0], h.shape[0], h_out.shape[0]) >= n_rows
+    call('tst_gru_cell_fused_f32', _p(x), x.stride(0), _p(h), h.stride(0), _p(wih), wih.stride(0), _p(bih), _p(whh), whh.stride(0),
+         _p(bhh), _p(h_out), h_out.stride(0), n_rows, E, H, _stream())
+
+
 def gather_rows(src, idx, dst, n_rows):
     _chk(src, torch.float32, 'src'); _chk(dst, torch.float32, 'dst'); _chk(idx, torch.int32, 'idx')
     assert src.shape[1] == dst.shape[1]
@@ -251,7 +267,12 @@ class GruPlan:
                                  ld_logits=logits.stride(0), layers=self._layers)
 
     def run(self, rows, n_rows, phases):
+        """With ``STEP_FUSED_CELL`` in ``phases`` (and the layers run) the new state of every layer lands in ``h_alt``: the
+        pointers are swapped here, the caller swaps its tensors."""
         call('tst_gru_step_run', self.c, _p(rows.tok), _p(rows.sent), n_rows, phases, _stream())
+        if phases & STEP_FUSED_CELL and phases & STEP_LAYERS:
+            for L in self._layers:
+                L.h, L.h_alt = L.h_alt, L.h
 
     def reorder(self, row_parent, n_rows):
         call('tst_gru_reorder_run', self.c, _p(row_parent), n_rows, _stream())

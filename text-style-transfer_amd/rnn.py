@@ -12,6 +12,7 @@ n_layers GRU (PyTorch gate order and formula) -> linear to raw logits.  The deco
 state instead of re-running the prefix (``/root/reference/src/inference.py:132`` re-runs it).
 """
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -153,6 +154,11 @@ class ConditionalLM(_GRUModel):
         return (logits, z_new) if return_z else logits
 
 
+# rows from which the one-kernel GRU cell is used: below, 128 x 64 tiles leave most compute units without work and the
+# small-problem GEMM kernels of the three-call form are faster
+FUSED_MIN_ROWS = int(os.environ.get('TST_GRU_FUSED_MIN_ROWS', '2048'))   # measured crossover at E = H = 1024: between 1024 and 2048 rows
+
+
 class GRUSession:
     """Carried hidden state [layer][row][H] (two buffers per layer: rows are re-gathered when the batch
     is compacted or beams are reordered) and work buffers.  ``extra`` [B, E]: a vector per sentence that is added
@@ -204,7 +210,14 @@ class GRUSession:
             phases |= K.STEP_EMBED
         else:   # token distributions instead of ids: expected embedding
             K.soft_embed(soft, self.m.soft_embedding_matrix(), 1.0, None, self.x, n)
+        # from FUSED_MIN_ROWS rows on every layer's cell is one kernel (gate pre-activations stay in the matrix-core accumulators);
+        # it writes the new state to the other buffer of the pair
+        fused = n >= FUSED_MIN_ROWS and K.gru_cell_fused_ok(self.m.E, self.m.H)
+        if fused:
+            phases |= K.STEP_FUSED_CELL
         self._plan().run(rows, n, phases)
+        if fused:
+            self.h, self.h_alt = self.h_alt, self.h
         return self.logits
 
 

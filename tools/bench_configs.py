@@ -57,6 +57,31 @@ def cfg1(n_sent, bias=None):
         run('cfg1 transformer-mt V=32000 greedy fp32 max_len=50 (encoder included)', make, B, repeats=5)
 
 
+def gru_cell_roofline(model, rows):
+    """The GRU cell step alone (x Wih, h Whh and the gate update as one kernel) at `rows` rows, HIP events over 20 launches:
+    algorithmic work 2 * rows * 3H * (E + H) FLOP against the dense fp32 matrix peak of MI355X (157.3 TFLOP/s)."""
+    from tst_amd import kernels as K
+    W = model.prepared()['cells'][0]
+    E, H = W['wih'].shape[0], W['whh'].shape[0]
+    x = torch.randn((rows, E), device=model.device)
+    h = torch.randn((rows, H), device=model.device)
+    out = torch.empty_like(h)
+    fn = lambda: K.gru_cell_fused(x, h, W['wih'], W['bih'], W['whh'], W['bhh'], out, rows)   # noqa: E731
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(20):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 20 * 1e3
+    tf = 2.0 * rows * 3 * H * (E + H) / us / 1e6
+    print(json.dumps({'kernel': 'gru_fused_kernel (GRU cell step, E=%d H=%d)' % (E, H), 'rows': rows, 'avg_launch_us': round(us, 1),
+                      'roofline': {'bound': 'mfma', 'achieved': round(tf, 1), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(tf / 157.3, 3)}}),
+          flush=True)
+
+
 def cfg3(n_sent, bias=None):
     dev = torch.device('cuda', 0)
     for V, eos_bias in ((128, 0.5), (32000, 1.0)):
@@ -66,6 +91,7 @@ def cfg3(n_sent, bias=None):
         model.load_state_dict(synthetic.synthetic_state_dict(model, vocab.stoi['|'], eos_bias, 2.0, seed=42))
         z = torch.randn((n_sent, 1024), generator=torch.Generator().manual_seed(1237)).to(dev)
         for beam in (1, 4):
+            gru_cell_roofline(model, n_sent * beam)
             run('cfg3 GRU H=1024 V=%d beam=%d fp32 max_len=100' % (V, beam),
                 lambda: tst_amd.InferenceState({'model': model, 'inputs': z, 'vocab': vocab, 'max_len': 100, 'eos_token': '|',
                                                 'beam_size': beam}), n_sent)
