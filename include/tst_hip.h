@@ -32,7 +32,8 @@ extern "C" {
  * tst_tfm_step_run, tst_gru_step_run, tst_gru_reorder_run, tst_select_step_run,
  * tst_attn_cross_group_f32, tst_ln_gemm_f32,
  * tst_greedy_retire_compact; 102 = 101 + tst_retire_compact_noalloc;
- * 103 = 102 + tst_gru_cell_fused_f32, tst_gru_cell_fused_ok, TST_STEP_FUSED_CELL (additions only). */
+ * 103 = 102 + tst_gru_cell_fused_f32, tst_gru_cell_fused_ok, TST_STEP_FUSED_CELL;
+ * 104 = 103 + tst_gemm_dma_f32, tst_layernorm_t_f32, tst_tfm_step.ht / ld_ht (additions only). */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
@@ -60,6 +61,21 @@ int tst_layernorm_f32(const float* x, const float* gamma, const float* beta, flo
  * 16-byte aligned A and Wt. */
 int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res,
                       int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream);
+
+/* C[M][N] = bias[n] + sum_k A[m][k] * Wt[k][n] with A given K-MAJOR, AT[k][m] (tst_layernorm_t_f32 writes it so): both
+ * operand tiles are then contiguous row pieces and are staged by LDS-DMA (global_load_lds) instead of through registers.
+ * Same fma chain per element as tst_gemm_mfma_f32, hence bit-identical results.  For the vocabulary projection of large
+ * batches (nn.Linear d_model -> V of the model called at /root/reference/src/inference.py:132).
+ * K % 16 == 0; ldat a multiple of 4 and >= M rounded up to a multiple of 128 (columns of AT beyond M may hold anything);
+ * ldw % 4 == 0, ldw >= N; AT and Wt 16-byte aligned.  variant: 0 = tiles of 16 k in a ring of 3, 1 = 8 k x 4, 2 = 8 k x 6
+ * (tuning; same results). */
+int tst_gemm_dma_f32(const float* AT, int64_t ldat, const float* Wt, int64_t ldw, const float* bias, float* C, int64_t ldc,
+                     int64_t M, int64_t N, int64_t K, int variant, void* stream);
+
+/* yT[k][r] = LayerNorm(x)[r][k]: tst_layernorm_f32 with the result stored k-major (ldt >= R floats per k), the operand
+ * layout of tst_gemm_dma_f32.  Same statistics and affine map, element for element.  d % 4 == 0, d <= 512. */
+int tst_layernorm_t_f32(const float* x, const float* gamma, const float* beta, float eps, float* yT, int64_t ldt, int64_t R,
+                        int64_t d, void* stream);
 
 /* The same product by the kernel that tst_gemm_mfma_f32 chooses for small M * N: one wave per 16 x (16 * strip) strip of
  * C (strip = 1, 2 or 4) on v_mfma_f32_16x16x4_f32.  Same arguments, same requirements, bit-identical results (every
@@ -304,7 +320,12 @@ typedef struct tst_tfm_step {
     void* logits;           /* [rows][ld_logits] output */
     int64_t ld_logits;
     const tst_tfm_layer* layers;          /* host array of n_layers */
+    float* ht;              /* fp32 only, optional: [d][ld_ht] k-major copy target of the final LayerNorm.  When set and the
+                               step has at least TST_DMA_MIN_ROWS rows, the final LayerNorm writes here (tst_layernorm_t_f32)
+                               and the vocabulary projection is tst_gemm_dma_f32; h is then not written.  Same logits. */
+    int64_t ld_ht;          /* >= slab_rows rounded up to a multiple of 128 */
 } tst_tfm_step;
+#define TST_DMA_MIN_ROWS 2048
 
 #define TST_STEP_EMBED 1   /* x = emb[tok] * scale + pe[t] (+ z[sent]); without it x must hold the embeddings */
 #define TST_STEP_LAYERS 2  /* the layer stack and the final LayerNorm (into h) */

@@ -311,3 +311,36 @@ def test_gru_cell_fused_equals_three_call_form_and_oracle(K, R, E, H):
     with pytest.raises(_lib.TstError, match='must not overlap'):
         K.gru_cell_fused(xd, hd, wi, bi, wh, bh, hd, R)
     assert not K.gru_cell_fused_ok(1024, 1000) and not K.gru_cell_fused_ok(1028, 1024) and K.gru_cell_fused_ok(1024, 1024)
+
+
+@pytest.mark.parametrize('M,N,Kd', [(300, 700, 64), (2049, 1000, 256), (128, 256, 16), (5, 32000, 256), (1000, 515, 512)])
+@pytest.mark.parametrize('variant', [0, 2, 3])
+def test_gemm_dma_k_major_activations_bit_exact(K, M, N, Kd, variant):
+    """Both operands staged by LDS-DMA (activations given k-major): the same fma chain per element as the register-staged
+    kernel and the oracle, so ``==``; columns of the k-major operand beyond M hold garbage on purpose."""
+    r = rs(M + N + Kd)
+    a = r.standard_normal((M, Kd)).astype(np.float32)
+    w = (r.standard_normal((Kd, N)) / np.sqrt(Kd)).astype(np.float32)
+    b = r.standard_normal(N).astype(np.float32)
+    ldw = (N + 3) // 4 * 4
+    wd = torch.zeros((Kd, ldw), device='cuda'); wd[:, :N] = dev(w)
+    ld = (M + 127) // 128 * 128
+    at = torch.full((Kd, ld), 1e30, device='cuda')
+    at[:, :M] = dev(a).t()
+    out = torch.full((M + 1, ldw + 4), 7.0, device='cuda')
+    K.gemm_dma(at, wd[:, :N], dev(b), out, M, variant=variant)
+    assert np.array_equal(out[:M, :N].cpu().numpy(), C.gemm(a, w, b))
+    assert (out[M:] == 7.0).all() and (out[:, N:] == 7.0).all()
+
+
+@pytest.mark.parametrize('R,d', [(130, 256), (64, 512), (1, 32), (1000, 64)])
+def test_layernorm_k_major_output_equals_layernorm(K, R, d):
+    r = rs(R + d)
+    x = (r.standard_normal((R, d)) * 3).astype(np.float32)
+    g, b = r.standard_normal(d).astype(np.float32), r.standard_normal(d).astype(np.float32)
+    y = torch.empty((R, d), device='cuda')
+    K.layernorm(dev(x), dev(g), dev(b), y, R)
+    yt = torch.full((d, R + 9), 7.0, device='cuda')
+    K.layernorm_t(dev(x), dev(g), dev(b), yt, R)
+    assert torch.equal(yt[:, :R], y.t()) and (yt[:, R:] == 7.0).all()
+    assert np.array_equal(y.cpu().numpy(), C.layernorm(x, g, b))

@@ -44,7 +44,7 @@ class TstTfmStep(ctypes.Structure):
                 ('z', c_vp), ('mask', c_vp), ('kvrow', c_vp), ('ln_g', c_vp), ('ln_b', c_vp),
                 ('wout', c_vp), ('bout', c_vp), ('ld_wout', c_i64),
                 ('x', c_vp), ('h', c_vp), ('q', c_vp), ('a', c_vp), ('ff', c_vp), ('logits', c_vp), ('ld_logits', c_i64),
-                ('layers', ctypes.POINTER(TstTfmLayer))]
+                ('layers', ctypes.POINTER(TstTfmLayer)), ('ht', c_vp), ('ld_ht', c_i64)]
 
 
 class TstGruLayer(ctypes.Structure):
@@ -81,6 +81,8 @@ _PROTOS = {
     'tst_scale_posadd_f32': ([c_vp, c_f32, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_layernorm_f32': ([c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_gemm_mfma_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp], c_int),
+    'tst_gemm_dma_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp], c_int),
+    'tst_layernorm_t_f32': ([c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_gemm_skinny_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp], c_int),
     'tst_ln_gemm_f32': ([c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp], c_int),
     'tst_attn_self_step_f32': ([c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),

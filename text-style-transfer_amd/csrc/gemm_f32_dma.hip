@@ -1,0 +1,255 @@
+// fp32 GEMM for the vocabulary projection with BOTH operands staged by LDS-DMA: C = bias + A * Wt, A given k-major.
+//
+// gemm_f32_kernel stages its tiles through registers (global_load -> VGPR -> ds_write) because the row-major activations
+// have to be transposed into the k-major LDS image the one-float-per-lane MFMA operands want.  When the producer of A
+// writes it k-major (AT[k][m]: tst_layernorm_t_f32), a k-tile of either operand is a set of contiguous row pieces, and
+// global_load_lds (16 bytes per lane, 1 KiB per wave-instruction, lane-linear in LDS) lands it in exactly that image:
+// no staging registers, no LDS store instructions, and the tile loads of the next stages stay in flight across barriers.
+// Every output element is still acc = bias[n]; for k ascending: acc = fma(A[m][k], Wt[k][n], acc) on
+// v_mfma_f32_32x32x2_f32, so results are bit-identical to gemm_f32_kernel.
+// Tile 128 x 256 x BK per 256-thread workgroup (4 waves as 2 x 2, 64 x 128 per wave), NST stages in a ring.  Operand
+// reads are inline assembly with explicit waits: the compiler would order every LDS read behind ALL pending LDS-DMA.
+#include "tst_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void glb_void_t;
+
+namespace {
+
+constexpr int TM = 128, TN = 256, GROUP_M = 16;
+
+template <int BK, int NST, bool READ2>
+__global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __restrict__ AT, int64_t ldat, const float* __restrict__ W,
+                                                              int64_t ldw, const float* __restrict__ bias, float* C, int64_t ldc, int M,
+                                                              int N, int K, int tiles_m, int tiles_n) {
+    constexpr int A_BYTES = BK * TM * 4, B_BYTES = BK * TN * 4, STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = A_BYTES / 4096, NB = B_BYTES / 4096, NDMA = NA + NB;   // wave-instructions per wave and tile
+    static_assert(A_BYTES % 4096 == 0 && NST >= 3, "tile shape");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
+    const int lb = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    const int per_group = GROUP_M * tiles_n;
+    const int first_m = (lb / per_group) * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (lb % per_group) % gsz;
+    const int tn = (lb % per_group) / gsz;
+    const int m0 = tm * TM, n0 = tn * TN;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // DMA sources.  A piece (1 KiB) is two k-rows of the A tile (128 floats each): lane l -> k = 2 p + (l >> 5),
+    // m = 4 (l & 31); a piece of the Wt tile is one k-row (256 floats): lane l -> n = 4 l.  Wave w moves pieces w, w + 4, ...
+    // The rows of AT are ldat >= tiles_m * 128 floats long, so the tile's columns always exist (columns beyond M hold
+    // stale values whose products are never stored); columns of Wt beyond ldw are clamped.
+    const float* a_src = AT + (int64_t)(2 * wave + (lane >> 5)) * ldat + m0 + 4 * (lane & 31);
+    const float* w_src = W + (int64_t)wave * ldw + min(n0 + 4 * lane, (int)ldw - 4);
+    auto stage = [&](int st, int k0) {
+        unsigned char* base = smem + st * STAGE + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src + (int64_t)(k0 + 8 * j) * ldat), (lds_void_t*)(base + j * 4096), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(w_src + (int64_t)(k0 + 4 * j) * ldw), (lds_void_t*)(base + A_BYTES + j * 4096), 16, 0,
+                                             0);
+    };
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int col = n0 + wn * 128 + j * 32 + (lane & 31);
+        const float b = (bias != nullptr && col < N) ? bias[col] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = b;
+    }
+
+    // operand of MFMA step s (k = 2 s + khalf) of a stage: A image [k][128], Wt image [k][256]
+    const int khalf = lane >> 5;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const uint32_t a_off = lds_base + (khalf * TM + wm * 64 + (lane & 31)) * 4;
+    const uint32_t b_off = lds_base + A_BYTES + (khalf * TN + wn * 128 + (lane & 31)) * 4;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2 fa[2][1], fb[2][2];   // two operand sets: the one being multiplied and the one being read; pairs are 32 columns apart
+#define TST_DS_READ(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define TST_DS_READ2(dst, addr, o0, o1) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(o0), "n"(o1))
+    auto read_step = [&](int set, uint32_t as, uint32_t bs) {
+        if (READ2) {   // one instruction per operand pair (offsets in dwords)
+            TST_DS_READ2(fa[set][0], as, 0, 32);
+            TST_DS_READ2(fb[set][0], bs, 0, 32);
+            TST_DS_READ2(fb[set][1], bs, 64, 96);
+        } else {
+            TST_DS_READ(fa[set][0].x, as, 0);
+            TST_DS_READ(fa[set][0].y, as, 128);
+            TST_DS_READ(fb[set][0].x, bs, 0);
+            TST_DS_READ(fb[set][0].y, bs, 128);
+            TST_DS_READ(fb[set][1].x, bs, 256);
+            TST_DS_READ(fb[set][1].y, bs, 384);
+        }
+    };
+    auto lds_wait = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    auto mfma_step = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][0][i], fb[set][j >> 1][j & 1], acc[i][j], 0, 0, 0);
+    };
+
+    // Ring of NST stages; tiles kt + 1 .. kt + NST - 2 are in flight while tile kt is multiplied.  In the middle of tile kt:
+    // wait until tile kt + 1 has landed (all but the NST - 3 youngest tiles), barrier (it also tells that every wave is past
+    // tile kt - 1), then the DMA of tile kt + NST - 1 goes into the stage tile kt - 1 used.  An LDS-DMA is complete for other
+    // waves only after the issuing wave has waited for it and both have passed a barrier.
+    constexpr int STEPS = BK / 2;
+    const int nkt = K / BK;
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p)
+        if (p < nkt) stage(p, p * BK);
+    if (nkt >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NST - 2)) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_step(0, a_off, b_off);
+    int st = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int st_next = st + 1 == NST ? 0 : st + 1;
+        const uint32_t as = a_off + st * STAGE, bs = b_off + st * STAGE;
+#pragma unroll
+        for (int s = 0; s < STEPS; ++s) {
+            lds_wait();                                          // operands of step s are in registers
+            if (s + 1 < STEPS) read_step((s + 1) & 1, as + (s + 1) * (2 * TM * 4), bs + (s + 1) * (2 * TN * 4));
+            else if (kt + 1 < nkt) read_step((s + 1) & 1, a_off + st_next * STAGE, b_off + st_next * STAGE);
+            mfma_step(s & 1);
+            if (s == STEPS / 2 - 1) {
+                if (kt + NST - 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NST - 3)) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (kt + NST - 1 < nkt) stage(st == 0 ? NST - 1 : st - 1, (kt + NST - 1) * BK);
+            }
+        }
+        st = st_next;
+    }
+#undef TST_DS_READ
+#undef TST_DS_READ2
+
+    // epilogue: lane owns column col of 16 rows per 32 x 32 tile (rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
+    const bool full_tile = m0 + TM <= M && n0 + TN <= N;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int col = n0 + wn * 128 + j * 32 + (lane & 31);
+            const int row0 = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+            if (full_tile) {
+                float* cp = C + (int64_t)row0 * ldc + col;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) cp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = acc[i][j][r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + (r & 3) + 8 * (r >> 2);
+                    if (col < N && row < M) C[(int64_t)row * ldc + col] = acc[i][j][r];
+                }
+            }
+        }
+}
+
+// y^T = LayerNorm(x)^T: the statistics and the affine map of layernorm_kernel (64 interleaved partial sums, xor-butterfly;
+// one wave per row), the normalised rows of a 64-row block collected in LDS and written k-major, yT[k][r], 64 consecutive
+// rows (256 bytes) per wave-instruction.
+__global__ __launch_bounds__(256) void layernorm_t_kernel(const float* __restrict__ x, const float* __restrict__ g, const float* __restrict__ b,
+                                                          float eps, float* __restrict__ yT, int64_t ldt, int64_t R, int d) {
+    extern __shared__ float tile[];   // [64][d + 1]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int d4 = d >> 2, ldl = d + 1;
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    for (int rr = wave; rr < 64; rr += 4) {
+        const int64_t r = r0 + rr;
+        if (r >= R) break;
+        const float4* xr = reinterpret_cast<const float4*>(x) + r * d4;
+        float p = 0.0f;
+        for (int c = lane; c < d4; c += 64) {
+            const float4 v = xr[c];
+            p = p + v.x; p = p + v.y; p = p + v.z; p = p + v.w;
+        }
+        const float dd = (float)d;
+        const float mean = wave_sum_butterfly(p) / dd;
+        p = 0.0f;
+        for (int c = lane; c < d4; c += 64) {
+            const float4 v = xr[c];
+            float t;
+            t = v.x - mean; p = __builtin_fmaf(t, t, p);
+            t = v.y - mean; p = __builtin_fmaf(t, t, p);
+            t = v.z - mean; p = __builtin_fmaf(t, t, p);
+            t = v.w - mean; p = __builtin_fmaf(t, t, p);
+        }
+        const float var = wave_sum_butterfly(p) / dd;
+        const float rstd = 1.0f / sqrtf(var + eps);
+        for (int c = lane; c < d4; c += 64) {
+            const float4 v = xr[c];
+            const float4 gg = reinterpret_cast<const float4*>(g)[c];
+            const float4 bb = reinterpret_cast<const float4*>(b)[c];
+            float* tp = tile + rr * ldl + 4 * c;
+            tp[0] = __builtin_fmaf((v.x - mean) * rstd, gg.x, bb.x);
+            tp[1] = __builtin_fmaf((v.y - mean) * rstd, gg.y, bb.y);
+            tp[2] = __builtin_fmaf((v.z - mean) * rstd, gg.z, bb.z);
+            tp[3] = __builtin_fmaf((v.w - mean) * rstd, gg.w, bb.w);
+        }
+    }
+    __syncthreads();
+    const int64_t r = r0 + lane;
+    if (r < R)
+        for (int k = wave; k < d; k += 4) yT[(int64_t)k * ldt + r] = tile[lane * ldl + k];
+}
+
+}  // namespace
+
+extern "C" int tst_layernorm_t_f32(const float* x, const float* gamma, const float* beta, float eps, float* yT, int64_t ldt, int64_t R,
+                                   int64_t d, void* stream) {
+    TST_REQUIRE(x && gamma && beta && yT, TST_ERR_ARG, "tst_layernorm_t_f32: null pointer");
+    TST_REQUIRE(R >= 0 && d >= 4 && d % 4 == 0 && ldt >= R, TST_ERR_ARG, "tst_layernorm_t_f32: bad sizes (d %% 4 == 0, ldt >= R)");
+    TST_REQUIRE(d <= 512, TST_ERR_UNSUPPORTED, "tst_layernorm_t_f32: rows of at most 512 elements (a 64-row block is staged in LDS)");
+    TST_REQUIRE(tst_aligned16(x) && tst_aligned16(gamma) && tst_aligned16(beta), TST_ERR_ARG, "tst_layernorm_t_f32: alignment");
+    if (R == 0) return TST_OK;
+    hipLaunchKernelGGL(layernorm_t_kernel, dim3((unsigned)((R + 63) / 64)), dim3(256), (size_t)(64 * (d + 1) * 4), (hipStream_t)stream, x,
+                       gamma, beta, eps, yT, ldt, R, (int)d);
+    return tst_after_launch("tst_layernorm_t_f32");
+}
+
+extern "C" int tst_gemm_dma_f32(const float* AT, int64_t ldat, const float* Wt, int64_t ldw, const float* bias, float* C, int64_t ldc,
+                                int64_t M, int64_t N, int64_t K, int variant, void* stream) {
+    TST_REQUIRE(AT && Wt && C, TST_ERR_ARG, "tst_gemm_dma_f32: null pointer");
+    TST_REQUIRE(M >= 0 && N > 0 && K >= 16 && K % 16 == 0, TST_ERR_ARG, "tst_gemm_dma_f32: bad sizes (K must be a multiple of 16)");
+    const int64_t tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
+    TST_REQUIRE(ldat % 4 == 0 && ldat >= tiles_m * TM && ldw % 4 == 0 && ldw >= N && ldw >= 4 && ldc >= N, TST_ERR_ARG,
+                "tst_gemm_dma_f32: ldat must be a multiple of 4 and at least M rounded up to 128; ldw %% 4 == 0, ldw >= N, ldc >= N");
+    TST_REQUIRE(tst_aligned16(AT) && tst_aligned16(Wt), TST_ERR_ARG, "tst_gemm_dma_f32: AT and Wt must be 16-byte aligned");
+    TST_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31) && tiles_m * tiles_n < (1ll << 31), TST_ERR_UNSUPPORTED,
+                "tst_gemm_dma_f32: size");
+    if (M == 0) return TST_OK;
+    const dim3 grid((unsigned)(tiles_m * tiles_n));
+    hipStream_t st = (hipStream_t)stream;
+#define TST_DMA_LAUNCH(BK_, NST_, R2_)                                                                                                \
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<BK_, NST_, R2_>), grid, dim3(256), 0, st, AT, ldat, Wt, ldw, bias, C, ldc, (int)M, (int)N, (int)K, \
+                       (int)tiles_m, (int)tiles_n)
+    switch (variant) {
+        case 1: TST_DMA_LAUNCH(8, 4, false); break;
+        case 2: TST_DMA_LAUNCH(8, 6, false); break;
+        case 3: TST_DMA_LAUNCH(8, 6, true); break;
+        case 4: TST_DMA_LAUNCH(8, 5, true); break;
+        case 5: TST_DMA_LAUNCH(16, 3, true); break;
+        default: TST_DMA_LAUNCH(16, 3, false); break;
+    }
+#undef TST_DMA_LAUNCH
+    return tst_after_launch("tst_gemm_dma_f32");
+}

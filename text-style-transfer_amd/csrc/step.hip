@@ -57,6 +57,10 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
     const int64_t d = m->d;
     const StepCtx c{m, R, stream, m->bf16 != 0};
     const int64_t esz = c.bf16 ? 2 : 4;
+    // large fp32 steps: the final LayerNorm writes its rows k-major and the vocabulary projection stages both operands by LDS-DMA
+    const bool dma_vocab = !c.bf16 && m->ht != nullptr && R >= TST_DMA_MIN_ROWS && d % 16 == 0 && d <= 512;
+    TST_REQUIRE(!dma_vocab || (m->ld_ht % 4 == 0 && m->ld_ht >= (R + 127) / 128 * 128), TST_ERR_ARG,
+                "tst_tfm_step_run: ld_ht must be a multiple of 4 and at least the rows rounded up to 128");
 
     if (phases & TST_STEP_EMBED) {
         TST_REQUIRE(tok && m->emb && m->pe, TST_ERR_ARG, "tst_tfm_step_run: null embedding input");
@@ -99,11 +103,16 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
             TST_TRY(c.ln_gemm(L.ln_ff_g, L.ln_ff_b, L.w1, L.ld_w1, L.b1, m->ff, m->d_ff, m->d_ff, 1));
             TST_TRY(c.gemm(m->ff, m->d_ff, L.w2, L.ld_w2, L.b2, m->x, d, m->x, d, d, m->d_ff, 0, false));
         }
-        TST_TRY(c.layernorm(m->x, m->ln_g, m->ln_b, m->h));
+        if (dma_vocab) TST_TRY(tst_layernorm_t_f32(m->x, m->ln_g, m->ln_b, m->eps, m->ht, m->ld_ht, R, d, stream));
+        else TST_TRY(c.layernorm(m->x, m->ln_g, m->ln_b, m->h));
     }
     if (phases & TST_STEP_VOCAB) {
         TST_REQUIRE(m->wout != nullptr, TST_ERR_ARG, "tst_tfm_step_run: null output projection");
-        TST_TRY(c.gemm(m->h, d, m->wout, m->ld_wout, m->bout, nullptr, 0, m->logits, m->ld_logits, m->V, d, 0, true));
+        if (dma_vocab)
+            TST_TRY(tst_gemm_dma_f32(m->ht, m->ld_ht, (const float*)m->wout, m->ld_wout, m->bout, (float*)m->logits, m->ld_logits, R, m->V, d,
+                                     2, stream));
+        else
+            TST_TRY(c.gemm(m->h, d, m->wout, m->ld_wout, m->bout, nullptr, 0, m->logits, m->ld_logits, m->V, d, 0, true));
     }
     return TST_OK;
 }

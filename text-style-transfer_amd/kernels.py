@@ -10,6 +10,8 @@ from . import _lib
 from ._lib import call, STEP_EMBED, STEP_LAYERS, STEP_VOCAB, STEP_FUSED_CELL  # noqa: F401
 
 
+DMA_MIN_ROWS = 2048   # TST_DMA_MIN_ROWS of include/tst_hip.h
+
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
 
@@ -138,6 +140,28 @@ def gemm(a, wt, bias, out, n_rows, n_cols=None, res=None, act=0, strip=None):
          _p(out), out.stride(0), n_rows, N, K, int(act), _stream())
 
 
+def gemm_dma(at, wt, bias, out, n_rows, n_cols=None, variant=0):
+    """out[:n_rows, :N] = at[:, :n_rows].T @ wt[:, :N] + bias with ``at`` [K, ld] k-major (ld >= n_rows rounded up to 128)."""
+    for t, nm in ((at, 'at'), (wt, 'wt'), (out, 'out'), (bias, 'bias')):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1):
+            raise ValueError('%s must be an fp32 GPU tensor with unit inner stride' % nm)
+    Kd = wt.shape[0]
+    N = wt.shape[1] if n_cols is None else n_cols
+    assert at.shape[0] == Kd and out.shape[1] >= N and out.shape[0] >= n_rows
+    call('tst_gemm_dma_f32', _p(at), at.stride(0), _p(wt), wt.stride(0), _p(bias), _p(out), out.stride(0), n_rows, N, Kd, int(variant),
+         _stream())
+
+
+def layernorm_t(x, gamma, beta, out_t, n_rows, eps=1e-5):
+    """out_t[k, r] = LayerNorm(x)[r, k] for r < n_rows; ``out_t`` [d, ld >= n_rows]"""
+    _chk(x, torch.float32, 'x'); _chk(gamma, torch.float32, 'gamma'); _chk(beta, torch.float32, 'beta')
+    if not (out_t.is_cuda and out_t.dtype == torch.float32 and out_t.stride(1) == 1):
+        raise ValueError('out_t must be an fp32 GPU tensor with unit inner stride')
+    d = x.shape[1]
+    assert out_t.shape[0] == d and out_t.shape[1] >= n_rows
+    call('tst_layernorm_t_f32', _p(x), _p(gamma), _p(beta), float(eps), _p(out_t), out_t.stride(0), n_rows, d, _stream())
+
+
 def attn_self_step(cache, anc, pos, out, n_rows, d, heads):
     """cache [n_pos, slab_rows, 3d] fp32 or bf16 (``out`` of the same type); anc [rows, T] int32"""
     _chk(cache, cache.dtype if cache.dtype == torch.bfloat16 else torch.float32, 'cache'); _chk(anc, torch.int32, 'anc')
@@ -228,8 +252,8 @@ class StepPlan:
     the leading dimension); the plan keeps every tensor alive."""
 
     def __init__(self, *, d, heads, d_ff, V, bf16, n_pos, slab_rows, S, anc_ld, emb, pe, scale, z, mask, ln, wout, bout,
-                 x, h, q, a, ff, logits, layers, eps=1e-5, kvrow=None, group=1):
-        self._keep = [kvrow, emb, pe, z, mask, ln, wout, bout, x, h, q, a, ff, logits, layers]
+                 x, h, q, a, ff, logits, layers, eps=1e-5, kvrow=None, group=1, ht=None):
+        self._keep = [kvrow, emb, pe, z, mask, ln, wout, bout, x, h, q, a, ff, logits, layers, ht]
         n = len(layers)
         self._layers = (_lib.TstTfmLayer * n)()
         for dst, L in zip(self._layers, layers):
@@ -243,7 +267,7 @@ class StepPlan:
             n_layers=n, d=d, heads=heads, d_ff=d_ff, V=V, bf16=int(bool(bf16)), group=int(group), n_pos=n_pos, slab_rows=slab_rows, S=S, anc_ld=anc_ld,
             emb=_p(emb), pe=_p(pe), scale=float(scale), eps=float(eps), z=_p(z), mask=_p(mask), kvrow=_p(kvrow), ln_g=_p(ln[0]), ln_b=_p(ln[1]),
             wout=_p(wout), bout=_p(bout), ld_wout=wout.stride(0), x=_p(x), h=_p(h), q=_p(q), a=_p(a), ff=_p(ff), logits=_p(logits),
-            ld_logits=logits.stride(0), layers=self._layers)
+            ld_logits=logits.stride(0), layers=self._layers, ht=_p(ht), ld_ht=0 if ht is None else ht.stride(0))
 
     def run(self, rows, n_rows, t, phases):
         call('tst_tfm_step_run', self.c, _p(rows.tok), _p(rows.anc), _p(rows.sent), n_rows, t, phases, _stream())

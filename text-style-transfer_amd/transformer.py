@@ -260,6 +260,9 @@ class TransformerSession:
         self.a = torch.empty((R, d), **f32)
         self.ff = torch.empty((R, dec.hp.d_ff), **f32)
         self.logits = torch.empty((R, (dec.V + 3) // 4 * 4), **f32)
+        # k-major target of the final LayerNorm for steps of many rows (the vocabulary projection then stages both operands by
+        # LDS-DMA); every row of it is long enough for the last 128-row tile
+        self.ht = torch.empty((d, (R + 127) // 128 * 128), **f32) if (R >= K.DMA_MIN_ROWS and d % 16 == 0 and d <= 512) else None
         self.scale = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
         self.max_len = max_len
         self._plans = {}
@@ -283,7 +286,7 @@ class TransformerSession:
                               S=self.S, anc_ld=anc_ld, emb=W['emb'], pe=W['pe'], scale=self.scale, z=None, mask=self.mask, kvrow=self.kvrow,
                               ln=W['ln'],
                               wout=W['wout'], bout=W['bout'], x=self.x, h=self.h, q=self.q, a=self.a, ff=self.ff, logits=self.logits,
-                              layers=layers)
+                              layers=layers, ht=self.ht)
             self._plans[anc_ld] = plan
         return plan
 
