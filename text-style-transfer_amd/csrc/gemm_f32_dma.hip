@@ -17,15 +17,24 @@ typedef const __attribute__((address_space(1))) void glb_void_t;
 
 namespace {
 
-constexpr int TM = 128, TN = 256, GROUP_M = 16;
+constexpr int TN = 256, GROUP_M = 16;
 
-template <int BK, int NST, bool READ2>
+// TM x 256 x BK tile per 256-thread workgroup, 4 waves as WVM x WVN, each with WTM x WTN MFMA tiles of 32 x 32.  Built
+// for 128 rows (2 x 2 waves, 2 x 4 tiles per wave): the vocabulary projection.  For the layer products (256 .. 1024
+// columns, K = 256 / 1024) 64- and 32-row tiles of this kernel, with residual / relu epilogues and k-major outputs, were
+// measured against gemm_f32_kernel at 4096 .. 32768 rows and were slower or equal in every case (those products are
+// short-K and close to the memory roofline: a row moves 3 KB per 131 kFLOP): not instantiated.
+// OUT_T: the product is computed transposed (operands swapped: the same fma chain per element), a lane then owns a ROW
+// and its 16 registers are 16 columns, and C (and res) are K-MAJOR, C[n][m]: 32 lanes store 128 contiguous bytes.
+template <int TM, int WVM, int WVN, int BK, int NST, bool HAS_RES, bool RELU, bool OUT_T>
 __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __restrict__ AT, int64_t ldat, const float* __restrict__ W,
-                                                              int64_t ldw, const float* __restrict__ bias, float* C, int64_t ldc, int M,
-                                                              int N, int K, int tiles_m, int tiles_n) {
+                                                              int64_t ldw, const float* __restrict__ bias, const float* res, int64_t ldr,
+                                                              float* C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr int WTM = TM / WVM / 32, WTN = TN / WVN / 32;
     constexpr int A_BYTES = BK * TM * 4, B_BYTES = BK * TN * 4, STAGE = A_BYTES + B_BYTES;
     constexpr int NA = A_BYTES / 4096, NB = B_BYTES / 4096, NDMA = NA + NB;   // wave-instructions per wave and tile
-    static_assert(A_BYTES % 4096 == 0 && NST >= 3, "tile shape");
+    constexpr int LPR = TM / 4, RPP = 64 / LPR;                               // lanes per A row, A rows per 1 KiB piece
+    static_assert(WVM * WVN == 4 && A_BYTES % 4096 == 0 && B_BYTES % 4096 == 0 && NST >= 3 && WTM >= 1 && WTN >= 1, "tile shape");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
 
     const int nwg = tiles_m * tiles_n;
@@ -41,58 +50,61 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __res
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WVN, wn = wave % WVN;
 
-    // DMA sources.  A piece (1 KiB) is two k-rows of the A tile (128 floats each): lane l -> k = 2 p + (l >> 5),
-    // m = 4 (l & 31); a piece of the Wt tile is one k-row (256 floats): lane l -> n = 4 l.  Wave w moves pieces w, w + 4, ...
-    // The rows of AT are ldat >= tiles_m * 128 floats long, so the tile's columns always exist (columns beyond M hold
+    // DMA sources.  A piece (1 KiB) is RPP k-rows of the A tile (TM floats each): lane l -> k = RPP p + l / LPR,
+    // m = 4 (l % LPR); a piece of the Wt tile is one k-row (256 floats): lane l -> n = 4 l.  Wave w moves pieces w, w + 4, ...
+    // The rows of AT are ldat >= tiles_m * TM floats long, so the tile's columns always exist (columns beyond M hold
     // stale values whose products are never stored); columns of Wt beyond ldw are clamped.
-    const float* a_src = AT + (int64_t)(2 * wave + (lane >> 5)) * ldat + m0 + 4 * (lane & 31);
+    const float* a_src = AT + (int64_t)(RPP * wave + lane / LPR) * ldat + m0 + 4 * (lane % LPR);
     const float* w_src = W + (int64_t)wave * ldw + min(n0 + 4 * lane, (int)ldw - 4);
     auto stage = [&](int st, int k0) {
         unsigned char* base = smem + st * STAGE + wave * 1024;
 #pragma unroll
         for (int j = 0; j < NA; ++j)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src + (int64_t)(k0 + 8 * j) * ldat), (lds_void_t*)(base + j * 4096), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src + (int64_t)(k0 + 4 * RPP * j) * ldat), (lds_void_t*)(base + j * 4096), 16, 0,
+                                             0);
 #pragma unroll
         for (int j = 0; j < NB; ++j)
             __builtin_amdgcn_global_load_lds((glb_void_t*)(w_src + (int64_t)(k0 + 4 * j) * ldw), (lds_void_t*)(base + A_BYTES + j * 4096), 16, 0,
                                              0);
     };
 
-    f32x16 acc[2][4];
+    // accumulators.  !OUT_T: lane owns column (lane & 31) of tile j, registers are 16 rows.  OUT_T: lane owns row
+    // (lane & 31) of tile i, registers are 16 columns c(r) = (r & 3) + 8 (r >> 2) + 4 (lane >> 5) of tile j.
+    f32x16 acc[WTM][WTN];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int col = n0 + wn * 128 + j * 32 + (lane & 31);
-        const float b = (bias != nullptr && col < N) ? bias[col] : 0.0f;
+    for (int j = 0; j < WTN; ++j) {
+        const int nb = n0 + wn * 32 * WTN + j * 32;
+        if (OUT_T) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int r = 0; r < 16; ++r) {
+                const int col = nb + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                const float b = (bias != nullptr && col < N) ? bias[col] : 0.0f;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = b;
+                for (int i = 0; i < WTM; ++i) acc[i][j][r] = b;
+            }
+        } else {
+            const int col = nb + (lane & 31);
+            const float b = (bias != nullptr && col < N) ? bias[col] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = b;
+        }
     }
 
-    // operand of MFMA step s (k = 2 s + khalf) of a stage: A image [k][128], Wt image [k][256]
+    // operand of MFMA step s (k = 2 s + khalf) of a stage: A image [k][TM], Wt image [k][256]
     const int khalf = lane >> 5;
     const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const uint32_t a_off = lds_base + (khalf * TM + wm * 64 + (lane & 31)) * 4;
-    const uint32_t b_off = lds_base + A_BYTES + (khalf * TN + wn * 128 + (lane & 31)) * 4;
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 fa[2][1], fb[2][2];   // two operand sets: the one being multiplied and the one being read; pairs are 32 columns apart
-#define TST_DS_READ(dst, addr, off) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
-#define TST_DS_READ2(dst, addr, o0, o1) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(o0), "n"(o1))
+    const uint32_t a_off = lds_base + (khalf * TM + wm * 32 * WTM + (lane & 31)) * 4;
+    const uint32_t b_off = lds_base + A_BYTES + (khalf * TN + wn * 32 * WTN + (lane & 31)) * 4;
+    float fa[2][WTM], fb[2][WTN];   // two operand sets: the one being multiplied and the one being read
     auto read_step = [&](int set, uint32_t as, uint32_t bs) {
-        if (READ2) {   // one instruction per operand pair (offsets in dwords)
-            TST_DS_READ2(fa[set][0], as, 0, 32);
-            TST_DS_READ2(fb[set][0], bs, 0, 32);
-            TST_DS_READ2(fb[set][1], bs, 64, 96);
-        } else {
-            TST_DS_READ(fa[set][0].x, as, 0);
-            TST_DS_READ(fa[set][0].y, as, 128);
-            TST_DS_READ(fb[set][0].x, bs, 0);
-            TST_DS_READ(fb[set][0].y, bs, 128);
-            TST_DS_READ(fb[set][1].x, bs, 256);
-            TST_DS_READ(fb[set][1].y, bs, 384);
-        }
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) asm volatile("ds_read_b32 %0, %1" : "=v"(fa[set][i]) : "v"(as + i * 128));
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) asm volatile("ds_read_b32 %0, %1" : "=v"(fb[set][j]) : "v"(bs + j * 128));
     };
     auto lds_wait = [&]() {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -100,10 +112,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __res
     };
     auto mfma_step = [&](int set) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < WTM; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][0][i], fb[set][j >> 1][j & 1], acc[i][j], 0, 0, 0);
+            for (int j = 0; j < WTN; ++j)
+                acc[i][j] = OUT_T ? __builtin_amdgcn_mfma_f32_32x32x2f32(fb[set][j], fa[set][i], acc[i][j], 0, 0, 0)
+                                  : __builtin_amdgcn_mfma_f32_32x32x2f32(fa[set][i], fb[set][j], acc[i][j], 0, 0, 0);
     };
 
     // Ring of NST stages; tiles kt + 1 .. kt + NST - 2 are in flight while tile kt is multiplied.  In the middle of tile kt:
@@ -128,6 +141,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __res
             lds_wait();                                          // operands of step s are in registers
             if (s + 1 < STEPS) read_step((s + 1) & 1, as + (s + 1) * (2 * TM * 4), bs + (s + 1) * (2 * TN * 4));
             else if (kt + 1 < nkt) read_step((s + 1) & 1, a_off + st_next * STAGE, b_off + st_next * STAGE);
+            // Left to the scheduler, the reads end up between the LAST MFMAs of the step.  Pinned in front of the step's MFMAs
+            // or one behind each of its first MFMAs, the 128-row tile lost 3-5 % (measured); the scheduler's placement stays.
             mfma_step(s & 1);
             if (s == STEPS / 2 - 1) {
                 if (kt + NST - 2 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NST - 3)) : "memory");
@@ -139,26 +154,51 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __res
         }
         st = st_next;
     }
-#undef TST_DS_READ
-#undef TST_DS_READ2
 
-    // epilogue: lane owns column col of 16 rows per 32 x 32 tile (rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
     const bool full_tile = m0 + TM <= M && n0 + TN <= N;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int col = n0 + wn * 128 + j * 32 + (lane & 31);
-            const int row0 = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
-            if (full_tile) {
-                float* cp = C + (int64_t)row0 * ldc + col;
+        for (int j = 0; j < WTN; ++j) {
+            if (OUT_T) {
+                // lane owns row `row`; register r is column c(r): C[col][row], 32 lanes = 128 contiguous bytes
+                const int row = m0 + wm * 32 * WTM + i * 32 + (lane & 31);
+                const int col0 = n0 + wn * 32 * WTN + j * 32 + 4 * (lane >> 5);
+                float rv[16];
+                if (HAS_RES) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) cp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = acc[i][j][r];
+                    for (int r = 0; r < 16; ++r) {
+                        const int col = col0 + (r & 3) + 8 * (r >> 2);
+                        rv[r] = (full_tile || (col < N && row < M)) ? res[(int64_t)col * ldr + row] : 0.0f;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int col = col0 + (r & 3) + 8 * (r >> 2);
+                    float v = acc[i][j][r];
+                    if (RELU) v = v > 0.0f ? v : 0.0f;
+                    if (HAS_RES) v = v + rv[r];
+                    if (full_tile || (col < N && row < M)) C[(int64_t)col * ldc + row] = v;
+                }
             } else {
+                // lane owns column col of 16 rows per 32 x 32 tile (rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
+                const int col = n0 + wn * 32 * WTN + j * 32 + (lane & 31);
+                const int row0 = m0 + wm * 32 * WTM + i * 32 + 4 * (lane >> 5);
+                float rv[16];
+                if (HAS_RES) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row0 + (r & 3) + 8 * (r >> 2);
+                        rv[r] = (full_tile || (col < N && row < M)) ? res[(int64_t)row * ldr + col] : 0.0f;
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = row0 + (r & 3) + 8 * (r >> 2);
-                    if (col < N && row < M) C[(int64_t)row * ldc + col] = acc[i][j][r];
+                    float v = acc[i][j][r];
+                    if (RELU) v = v > 0.0f ? v : 0.0f;
+                    if (HAS_RES) v = v + rv[r];
+                    if (full_tile || (col < N && row < M)) C[(int64_t)row * ldc + col] = v;
                 }
             }
         }
@@ -226,30 +266,34 @@ extern "C" int tst_layernorm_t_f32(const float* x, const float* gamma, const flo
     return tst_after_launch("tst_layernorm_t_f32");
 }
 
+namespace {
+
+template <int BK, int NST>
+void launch_plain128(const float* AT, int64_t ldat, const float* Wt, int64_t ldw, const float* bias, float* C, int64_t ldc, int64_t M,
+                     int64_t N, int64_t K, hipStream_t st) {
+    const int64_t tiles_m = (M + 127) / 128, tiles_n = (N + TN - 1) / TN;
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<128, 2, 2, BK, NST, false, false, false>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st,
+                       AT, ldat, Wt, ldw, bias, nullptr, 0, C, ldc, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n);
+}
+
+}  // namespace
+
 extern "C" int tst_gemm_dma_f32(const float* AT, int64_t ldat, const float* Wt, int64_t ldw, const float* bias, float* C, int64_t ldc,
                                 int64_t M, int64_t N, int64_t K, int variant, void* stream) {
     TST_REQUIRE(AT && Wt && C, TST_ERR_ARG, "tst_gemm_dma_f32: null pointer");
     TST_REQUIRE(M >= 0 && N > 0 && K >= 16 && K % 16 == 0, TST_ERR_ARG, "tst_gemm_dma_f32: bad sizes (K must be a multiple of 16)");
-    const int64_t tiles_m = (M + TM - 1) / TM, tiles_n = (N + TN - 1) / TN;
-    TST_REQUIRE(ldat % 4 == 0 && ldat >= tiles_m * TM && ldw % 4 == 0 && ldw >= N && ldw >= 4 && ldc >= N, TST_ERR_ARG,
+    const int64_t tiles_m = (M + 127) / 128, tiles_n = (N + TN - 1) / TN;
+    TST_REQUIRE(ldat % 4 == 0 && ldat >= tiles_m * 128 && ldw % 4 == 0 && ldw >= N && ldw >= 4 && ldc >= N, TST_ERR_ARG,
                 "tst_gemm_dma_f32: ldat must be a multiple of 4 and at least M rounded up to 128; ldw %% 4 == 0, ldw >= N, ldc >= N");
     TST_REQUIRE(tst_aligned16(AT) && tst_aligned16(Wt), TST_ERR_ARG, "tst_gemm_dma_f32: AT and Wt must be 16-byte aligned");
     TST_REQUIRE(M < (1ll << 31) && N < (1ll << 31) && K < (1ll << 31) && tiles_m * tiles_n < (1ll << 31), TST_ERR_UNSUPPORTED,
                 "tst_gemm_dma_f32: size");
     if (M == 0) return TST_OK;
-    const dim3 grid((unsigned)(tiles_m * tiles_n));
     hipStream_t st = (hipStream_t)stream;
-#define TST_DMA_LAUNCH(BK_, NST_, R2_)                                                                                                \
-    hipLaunchKernelGGL((gemm_f32_dma_kernel<BK_, NST_, R2_>), grid, dim3(256), 0, st, AT, ldat, Wt, ldw, bias, C, ldc, (int)M, (int)N, (int)K, \
-                       (int)tiles_m, (int)tiles_n)
     switch (variant) {
-        case 1: TST_DMA_LAUNCH(8, 4, false); break;
-        case 2: TST_DMA_LAUNCH(8, 6, false); break;
-        case 3: TST_DMA_LAUNCH(8, 6, true); break;
-        case 4: TST_DMA_LAUNCH(8, 5, true); break;
-        case 5: TST_DMA_LAUNCH(16, 3, true); break;
-        default: TST_DMA_LAUNCH(16, 3, false); break;
+        case 1: launch_plain128<8, 4>(AT, ldat, Wt, ldw, bias, C, ldc, M, N, K, st); break;
+        case 0: launch_plain128<16, 3>(AT, ldat, Wt, ldw, bias, C, ldc, M, N, K, st); break;
+        default: launch_plain128<8, 6>(AT, ldat, Wt, ldw, bias, C, ldc, M, N, K, st); break;
     }
-#undef TST_DMA_LAUNCH
     return tst_after_launch("tst_gemm_dma_f32");
 }
