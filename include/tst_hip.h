@@ -33,7 +33,8 @@ extern "C" {
  * tst_attn_cross_group_f32, tst_ln_gemm_f32,
  * tst_greedy_retire_compact; 102 = 101 + tst_retire_compact_noalloc;
  * 103 = 102 + tst_gru_cell_fused_f32, tst_gru_cell_fused_ok, TST_STEP_FUSED_CELL;
- * 104 = 103 + tst_gemm_dma_f32, tst_layernorm_t_f32, tst_tfm_step.ht / ld_ht (additions only). */
+ * 104 = 103 + tst_gemm_dma_f32, tst_layernorm_t_f32, tst_tfm_step.ht / ld_ht, tst_attn_cross_mfma_f32
+ * (additions only). */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
@@ -138,6 +139,15 @@ int tst_attn_cross_packed_f32(const float* q, const float* kv, const uint8_t* ma
  * [n_sent][S][2*d]; else kv is packed as for tst_attn_cross_packed_f32.  Results are identical to those entry points. */
 int tst_attn_cross_group_f32(const float* q, const float* kv, const uint8_t* mask, const int32_t* sent, const int32_t* kvrow,
                              int64_t S, float* out, int64_t R, int64_t d, int64_t heads, int64_t group, void* stream);
+
+/* tst_attn_cross_group_f32 with the beams of a sentence as the rows of matrix-core products: per (sentence, head) the
+ * scores are Q [beams x dh] K^T and the outputs W [beams x S] V on v_mfma_f32_4x4x1_16B_f32, the key tile staged once in
+ * LDS.  The score dot products are single fma chains over the head's elements (the other kernels sum 16 partials), so
+ * results agree with tst_attn_cross_group_f32 to the last bits only; softmax and value sums are the same.  Needs
+ * R % group == 0, group 2..8, S <= 64, head size 4, 8, 16, 32, 64 or 128 (TST_ERR_UNSUPPORTED otherwise).  Measured slower
+ * than tst_attn_cross_group_f32 at the benchmark sizes and therefore not used by tst_tfm_step_run. */
+int tst_attn_cross_mfma_f32(const float* q, const float* kv, const uint8_t* mask, const int32_t* sent, const int32_t* kvrow,
+                            int64_t S, float* out, int64_t R, int64_t d, int64_t heads, int64_t group, void* stream);
 
 /* The two attention steps with bf16 cache / q / k|v / output (same layouts, 2-byte elements); scores,
  * softmax and the value sum are computed in fp32 in the same order as the fp32 kernels. */

@@ -174,12 +174,20 @@ static float dot16(const float* a, const float* b, int64_t dh) {
     return sum_butterfly(p, 16);
 }
 
+/* the same dot product as ONE chain: acc = 0; for e ascending: acc = fma(a[e], b[e], acc) (the order of a matrix-core
+ * product: the cross-attention of beam groups computes the scores of a sentence's beams as Q K^T on the MFMA units) */
+static float dot_chain(const float* a, const float* b, int64_t dh) {
+    float acc = 0.0f;
+    for (int64_t e = 0; e < dh; ++e) acc = fmaf(a[e], b[e], acc);
+    return acc;
+}
+
 /* q, out: [R][heads*dh].  K, V: [n_entries][n_stride][heads*dh]; row r attends to entry kv_row[r],
  * positions 0..n-1; mask (optional) [n_entries][n_stride] bytes, 0 = position excluded.
- * scores s_p = dot16(q, K_p) * scale; w_p = exp(s_p - max) / sum (64 interleaved partials + butterfly);
+ * scores s_p = dot16(q, K_p) * scale (chain != 0: dot_chain); w_p = exp(s_p - max) / sum (64 interleaved partials + butterfly);
  * out[c] = sum_p fma(w_p, V_p[c], acc), p ascending. */
 void orc_attention(const float* q, const float* K, const float* V, const int32_t* kv_row, const uint8_t* mask,
-                   int64_t R, int64_t n, int64_t n_stride, int64_t heads, int64_t dh, float scale, float* out) {
+                   int64_t R, int64_t n, int64_t n_stride, int64_t heads, int64_t dh, float scale, float* out, int chain) {
     int64_t d = heads * dh;
 #pragma omp parallel for
     for (int64_t r = 0; r < R; ++r) {
@@ -190,7 +198,8 @@ void orc_attention(const float* q, const float* K, const float* V, const int32_t
             float mx = -INFINITY;
             for (int64_t p = 0; p < n; ++p) {
                 if (mask && !mask[ent * n_stride + p]) { s[p] = -INFINITY; continue; }
-                s[p] = dot16(qh, K + (ent * n_stride + p) * d + h * dh, dh) * scale;
+                const float* kp = K + (ent * n_stride + p) * d + h * dh;
+                s[p] = (chain ? dot_chain(qh, kp, dh) : dot16(qh, kp, dh)) * scale;
                 if (s[p] > mx) mx = s[p];
             }
             float part[64];

@@ -103,8 +103,10 @@ def layernorm(x, g, b, eps=1e-5):
     return y
 
 
-def attention(q, K, V, kv_row, mask, n, heads):
-    """q [R,d]; K,V [E,n_stride,d]; kv_row [R] or None; mask [E,n_stride] (nonzero = attend) or None."""
+def attention(q, K, V, kv_row, mask, n, heads, chain=False):
+    """q [R,d]; K,V [E,n_stride,d]; kv_row [R] or None; mask [E,n_stride] (nonzero = attend) or None.
+    ``chain``: the score dot products are single fma chains instead of 16 partial sums (the order of the matrix-core
+    cross-attention kernel, which is not on the decode path)."""
     q, pq = _f(q)
     K, pK = _f(K)
     V, pV = _f(V)
@@ -118,7 +120,7 @@ def attention(q, K, V, kv_row, mask, n, heads):
         mask = np.ascontiguousarray(mask, dtype=np.uint8)
         pm = mask.ctypes.data_as(_u8p)
     lib().orc_attention(pq, pK, pV, pk, pm, _i64(R), _i64(n), _i64(K.shape[1]), _i64(heads), _i64(dh),
-                        ctypes.c_float(np.float32(1.0 / math.sqrt(dh))), out.ctypes.data_as(_f32p))
+                        ctypes.c_float(np.float32(1.0 / math.sqrt(dh))), out.ctypes.data_as(_f32p), ctypes.c_int(int(bool(chain))))
     return out
 
 
@@ -213,6 +215,7 @@ class _TransformerSession:
         self.cv = [L['cv'](flat).reshape(B, S, d) for L in m.layers]
         self.S = S
         R = B * k
+        self.k = k
         self.sent = np.repeat(np.arange(B, dtype=np.int32), k)
         self.sk = [np.zeros((R, max_len, d), np.float32) for _ in m.layers]
         self.sv = [np.zeros((R, max_len, d), np.float32) for _ in m.layers]

@@ -165,7 +165,8 @@ def test_attn_cross_step_bit_exact(K, d, heads, S, masked):
 def test_attn_cross_group_bit_exact(K, d, heads, S, group):
     """Beams of a sentence as adjacent rows: keys / values loaded once per group.  Same bits as the oracle for groups that
     share a sentence, for groups that do not (computed row by row), with a packed k|v, and for the sizes the grouped
-    kernel is not built for (group 3, 64-element heads: the row-per-wave kernel runs)."""
+    kernel is not built for (group 3, 64-element heads: the row-per-wave kernel runs).  The matrix-core variant of the
+    kernel (keys staged in LDS, scores and outputs as MFMA products) equals the oracle with chain-order scores."""
     r = rs(d + S + group)
     B = 9
     n_groups = 11
@@ -182,6 +183,13 @@ def test_attn_cross_group_bit_exact(K, d, heads, S, group):
     out = torch.full((R, d), 7.0, dtype=torch.float32, device='cuda')
     K.attn_cross_step(dev(q), dev(kv), dev(mask), dev(sent), out, R, d, heads, group=group)
     assert np.array_equal(out.cpu().numpy(), want)
+    if S <= 64:   # the matrix-core kernel: scores as single fma chains, otherwise the same arithmetic
+        want_chain = C.attention(q, kv[:, :, :d], kv[:, :, d:], sent, mask, S, heads, chain=True)
+        assert not np.array_equal(want_chain, want)                       # the two orders differ in the last bits
+        np.testing.assert_allclose(want_chain, want, rtol=2e-5, atol=2e-6)
+        outm = torch.full((R, d), 7.0, dtype=torch.float32, device='cuda')
+        K.attn_cross_mfma(dev(q), dev(kv), dev(mask), dev(sent), outm, R, d, heads, group)
+        assert np.array_equal(outm.cpu().numpy(), want_chain)
     # packed k|v: only the unmasked positions exist
     live = mask.reshape(-1) != 0
     kvrow = (np.cumsum(live) - 1).astype(np.int32).reshape(B, S)

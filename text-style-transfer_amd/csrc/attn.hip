@@ -626,3 +626,19 @@ extern "C" int tst_attn_cross_step_bf16(const void* q, const void* kv, const uin
     return launch_attn<__bf16, false>((const __bf16*)kv, 0, nullptr, 0, (const __bf16*)q, mask, sent, S, (__bf16*)out, R, d,
                                       heads, (hipStream_t)stream, "tst_attn_cross_step_bf16");
 }
+
+// The same step with the beams of a sentence as the rows of matrix products on the matrix cores (attn_mfma.hip): scores in
+// chain order, so results differ from tst_attn_cross_group_f32 in the last bits.  Measured slower than that kernel at the
+// benchmark sizes (97 against 47 us per launch at 8192 sentences, beam 4, 2 heads of 128): exported for tests and tuning, not
+// used by tst_tfm_step_run.
+extern "C" int tst_attn_cross_mfma_f32(const float* q, const float* kv, const uint8_t* mask, const int32_t* sent, const int32_t* kvrow,
+                                       int64_t S, float* out, int64_t R, int64_t d, int64_t heads, int64_t group, void* stream) {
+    TST_REQUIRE(q && kv && sent && out, TST_ERR_ARG, "tst_attn_cross_mfma_f32: null pointer");
+    TST_REQUIRE(R >= 0 && d > 0 && heads > 0 && d % heads == 0 && S > 0 && group >= 1, TST_ERR_ARG, "tst_attn_cross_mfma_f32: bad sizes");
+    TST_REQUIRE(kvrow == nullptr || mask != nullptr, TST_ERR_ARG, "tst_attn_cross_mfma_f32: a packed k|v needs the mask");
+    TST_REQUIRE(R % group == 0 && tst_cross_mfma_ok(S, d / heads, group), TST_ERR_UNSUPPORTED,
+                "tst_attn_cross_mfma_f32: needs R %% group == 0, group 2..8, at most 64 positions and heads of 4, 8, .., 64 or 128 elements");
+    TST_REQUIRE(tst_aligned16(q) && tst_aligned16(kv) && tst_aligned16(out), TST_ERR_ARG, "tst_attn_cross_mfma_f32: alignment");
+    if (R == 0) return TST_OK;
+    return tst_launch_cross_mfma(kv, kvrow, q, mask, sent, S, out, R, d, heads, group, (hipStream_t)stream);
+}

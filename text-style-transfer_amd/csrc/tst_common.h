@@ -9,6 +9,11 @@
 
 void tst_set_error(const char* fmt, ...);
 
+// attn_mfma.hip: the matrix-core cross-attention of beam groups (used by tst_attn_cross_group_f32)
+int tst_cross_mfma_ok(int64_t S, int64_t dh, int64_t group);
+int tst_launch_cross_mfma(const float* kv, const int32_t* kvrow, const float* q, const uint8_t* mask, const int32_t* sent, int64_t S,
+                          float* out, int64_t R, int64_t d, int64_t heads, int64_t group, hipStream_t stream);
+
 #define TST_REQUIRE(cond, code, ...)                 \
     do {                                             \
         if (!(cond)) {                               \

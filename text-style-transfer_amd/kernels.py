@@ -192,6 +192,14 @@ def attn_cross_step(q, kv, mask, sent, out, n_rows, d, heads, kvrow=None, group=
     call('tst_attn_cross_step_bf16' if dt == torch.bfloat16 else 'tst_attn_cross_step_f32', _p(q), _p(kv), _p(mask), _p(sent), kv.shape[1], _p(out), n_rows, d, heads, _stream())
 
 
+def attn_cross_mfma(q, kv, mask, sent, out, n_rows, d, heads, group, kvrow=None):
+    """``attn_cross_step(..., group=)`` on the matrix cores (scores in chain order); fp32, S <= 64, group 2..8"""
+    _chk(q, torch.float32, 'q'); _chk(kv, torch.float32, 'kv'); _chk(mask, torch.uint8, 'mask'); _chk(sent, torch.int32, 'sent')
+    _chk(out, torch.float32, 'out'); _chk(kvrow, torch.int32, 'kvrow')
+    S = mask.shape[1] if mask is not None else kv.shape[1]
+    call('tst_attn_cross_mfma_f32', _p(q), _p(kv), _p(mask), _p(sent), _p(kvrow), S, _p(out), n_rows, d, heads, int(group), _stream())
+
+
 def gru_cell_step(gi, gh, h, h_out, n_rows):
     for t, nm in ((gi, 'gi'), (gh, 'gh'), (h, 'h'), (h_out, 'h_out')):
         _chk(t, torch.float32, nm)

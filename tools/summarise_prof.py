@@ -19,7 +19,7 @@ def open_db(d):
     hits = glob.glob(os.path.join(d, '**', '*results.db'), recursive=True)
     if not hits:
         raise SystemExit('no results.db under %s' % d)
-    return sqlite3.connect(hits[0])
+    return sqlite3.connect(max(hits, key=os.path.getsize))   # a run with child processes leaves one database per process: the bench's is the largest
 
 
 def label(name, grid, wg):
