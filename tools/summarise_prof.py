@@ -24,7 +24,9 @@ def open_db(d):
 
 def label(name, grid, wg):
     key = name.replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:90]
-    if 'gemm_' in key:
+    if 'gemm_f32_dma_kernel' in key:      # only the vocabulary projection uses the LDS-DMA kernel
+        key += ' [vocabulary projection]'
+    elif 'gemm_' in key:
         n = grid // max(1, wg)
         cols = 125 if '<2, 4,' in key else 250          # column tiles of N = 32000: 256- or 128-wide tiles
         key += ' [vocabulary projection]' if n >= cols and n % cols == 0 else ' [layer GEMMs]'
