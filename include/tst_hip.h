@@ -33,8 +33,8 @@ extern "C" {
  * tst_attn_cross_group_f32, tst_ln_gemm_f32,
  * tst_greedy_retire_compact; 102 = 101 + tst_retire_compact_noalloc;
  * 103 = 102 + tst_gru_cell_fused_f32, tst_gru_cell_fused_ok, TST_STEP_FUSED_CELL;
- * 104 = 103 + tst_gemm_dma_f32, tst_layernorm_t_f32, tst_tfm_step.ht / ld_ht, tst_attn_cross_mfma_f32
- * (additions only). */
+ * 104 = 103 + tst_gemm_dma_f32, tst_layernorm_t_f32, tst_tfm_step.ht / ld_ht, tst_attn_cross_mfma_f32,
+ * tst_select_step.n_sent_dev, tst_pack_sources, tst_scatter_rows_f32 (additions only). */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
@@ -177,6 +177,19 @@ int tst_gru_cell_fused_f32(const float* x, int64_t ldx, const float* h, int64_t 
 
 /* dst[r][:] = src[idx[r]][:], rows of `width` floats (width % 4 == 0); carried GRU state on reorder. */
 int tst_gather_rows_f32(const float* src, const int32_t* idx, float* dst, int64_t R, int64_t width, void* stream);
+
+/* dst[idx[r]][:] = src[r][:], rows of `width` floats (width % 4 == 0), idx without repeats: puts the packed encoder outputs
+ * back into the padded [B][S][d] tensor that /root/reference/src/trainers/transformer_mt_trainer.py:91 hands to the loop. */
+int tst_scatter_rows_f32(const float* src, const int32_t* idx, float* dst, int64_t R, int64_t width, void* stream);
+
+/* Packing of a right- or otherwise padded source batch src [B][S] (int64 token ids, `pad` = padding id), so that the encoder
+ * computes only real positions: mask [B][S] (1 = token), kvrow [B][S] = packed row of a token (-1 at padding), and for
+ * every packed row (sentence after sentence, positions ascending) its token, position, sentence and padded row b * S + p
+ * (arrays of B * S entries; the first n_live are written).  work: 2 * B int32 of scratch; n_live: device int32, the number
+ * of tokens.  Replaces the mask / nonzero / cumsum / index arithmetic around the encoder call of the reference's
+ * validation loop.  Three launches. */
+int tst_pack_sources(const int64_t* src, int64_t pad, int64_t B, int64_t S, uint8_t* mask, int32_t* kvrow, int32_t* tok,
+                     int32_t* pos, int32_t* sent, int32_t* padded_row, int32_t* work, int32_t* n_live, void* stream);
 
 /* tok[r] = index of the first maximal element of logits[r][0..V): torch.max(dim=-1)[1] at
  * /root/reference/src/inference.py:145. */
@@ -391,6 +404,10 @@ typedef struct tst_select_step {
     float temperature;  uint32_t seed;
     int32_t* out_tok;  int32_t* out_len;  float* out_score;  int32_t* scratch_alive_pos;  int32_t* row_parent;
     int32_t* n_alive;
+    const int32_t* n_sent_dev;   /* NULL, or device int32: the TRUE number of sentences entering the step, when the n_sent
+                                    argument of tst_select_step_run is only an upper bound (a caller that launches a step
+                                    before it has read the previous step's n_alive).  Sentences beyond it are ignored; the rows
+                                    the caller stepped for them are wasted work, nothing else.  Must not alias n_alive. */
 } tst_select_step;
 
 int tst_select_step_run(const tst_select_step* s, const tst_rows* cur, const tst_rows* nxt, int64_t n_sent, int64_t k_in,

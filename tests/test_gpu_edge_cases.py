@@ -144,3 +144,34 @@ def test_foreign_model_with_nan_logits_and_out_of_range_prefix_are_refused(T):
     with pytest.raises(IndexError):
         T.InferenceState({'model': gru, 'inputs': torch.zeros(2, 32).cuda(), 'vocab': vocab, 'max_len': 4,
                           'active_seqs': torch.tensor([[2, 50], [2, 5]])}).inference()
+
+
+@pytest.mark.parametrize('beam', [1, 4])
+def test_loop_without_per_step_count_read_equals_exact_loop(T, beam):
+    """Small batches launch a step before the previous step's survivor count has reached the host (the kernels take the true
+    count from device memory, the host's is an upper bound): outputs, scores and step count must equal the loop that reads
+    the count after every step; also for a GRU model, whose state rows are gathered on every step."""
+    from tst_amd import engine
+    tmodel, model, vocab, encs, mask = mt_case(T, 300, 37, 9, 2.0, 31)
+    old = engine.LAG_MAX_ROWS
+    outs = []
+    try:
+        for limit in (0, 1 << 20):
+            engine.LAG_MAX_ROWS = limit
+            got, st = decode(T, model, vocab, encs, mask, 14, beam)
+            assert st.loop.lagged == (limit > 0)
+            outs.append((got, st.scores.cpu().numpy().copy(), st.num_steps_done))
+        assert outs[0][0] == outs[1][0] and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+        assert outs[0][0] == oracle(tmodel, encs, mask, 14, beam)[0]
+        vg = T.Vocab.synthetic(60, extra=('|',))
+        gru = T.RNNLM(64, vg, 2)
+        z = torch.randn((2, 33, 64), generator=torch.Generator().manual_seed(5)).cuda()
+        res = []
+        for limit in (0, 1 << 20):
+            engine.LAG_MAX_ROWS = limit
+            st = T.InferenceState({'model': gru, 'inputs': z, 'vocab': vg, 'max_len': 12, 'bos_token': '|', 'eos_token': '|',
+                                   'substitute_inputs': True, 'inputs_batch_dim': 1, 'kwargs': {'return_z': True}, 'beam_size': beam})
+            res.append([s.tolist() for s in st.inference()])
+        assert res[0] == res[1]
+    finally:
+        engine.LAG_MAX_ROWS = old

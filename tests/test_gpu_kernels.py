@@ -352,3 +352,28 @@ def test_layernorm_k_major_output_equals_layernorm(K, R, d):
     K.layernorm_t(dev(x), dev(g), dev(b), yt, R)
     assert torch.equal(yt[:, :R], y.t()) and (yt[:, R:] == 7.0).all()
     assert np.array_equal(y.cpu().numpy(), C.layernorm(x, g, b))
+
+
+@pytest.mark.parametrize('B,S', [(7, 12), (300, 42), (1, 70), (1030, 5)])
+def test_pack_sources_and_scatter_rows(K, B, S):
+    r = rs(B + S)
+    src = r.randint(2, 50, size=(B, S)).astype(np.int64)
+    lens = r.randint(0, S + 1, size=B)
+    src[np.arange(S)[None] >= lens[:, None]] = 1                     # right padding with id 1, some sentences empty
+    if B > 3:
+        src[3, 0] = 1                                                 # and a hole in front
+    p = K.PackedSources(dev(src), 1)
+    live = src != 1
+    idx = np.flatnonzero(live.reshape(-1))
+    assert p.n == len(idx) and np.array_equal(p.mask.cpu().numpy(), live.astype(np.uint8))
+    assert np.array_equal(p.padded_row.cpu().numpy()[:p.n], idx)
+    assert np.array_equal(p.tok.cpu().numpy()[:p.n], src.reshape(-1)[idx]) and np.array_equal(p.pos.cpu().numpy()[:p.n], idx % S)
+    assert np.array_equal(p.sent.cpu().numpy()[:p.n], idx // S)
+    kvrow = p.kvrow.cpu().numpy()
+    assert np.array_equal(kvrow[live], np.arange(p.n)) and (kvrow[~live] == -1).all()
+    rows = torch.randn((max(p.n, 1), 8), device='cuda')
+    out = torch.zeros((B * S, 8), device='cuda')
+    K.scatter_rows(rows, p.padded_row, out, p.n)
+    want = np.zeros((B * S, 8), np.float32)
+    want[idx] = rows.cpu().numpy()[:p.n]
+    assert np.array_equal(out.cpu().numpy(), want)

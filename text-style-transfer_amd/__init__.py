@@ -14,6 +14,6 @@ from .rnn import CharLMFromEmbs, ConditionalLM, FFN, Generator, RNNDecoder, RNNE
 from .lm import TransformerLM
 from .postprocess import itos_many, compute_bleu_for_sents, corpus_bleu
 
-__all__ = ['InferenceState', 'simple_inference', 'Vocab', 'HP', 'Transformer', 'TransformerDecoder',
-           'TransformerEncoder', 'RNNDecoder', 'RNNEncoder', 'Generator', 'RNNLM', 'WeightedLMEnsemble', 'CharLMFromEmbs', 'TransformerLM', 'itos_many', 'compute_bleu_for_sents', 'corpus_bleu', 'TstError',
-           'version']
+__all__ = ['InferenceState', 'simple_inference', 'Vocab', 'HP', 'Transformer', 'TransformerDecoder', 'TransformerEncoder',
+           'RNNDecoder', 'RNNEncoder', 'Generator', 'FFN', 'RNNLM', 'ConditionalLM', 'WeightedLMEnsemble', 'CharLMFromEmbs',
+           'TransformerLM', 'itos_many', 'compute_bleu_for_sents', 'corpus_bleu', 'TstError', 'version']

@@ -69,7 +69,7 @@ class TstSelectStep(ctypes.Structure):
                 ('lp', c_vp), ('T', c_i64), ('top_ends', c_i32), ('sample', c_i32), ('temperature', c_f32),
                 ('seed', ctypes.c_uint32),
                 ('out_tok', c_vp), ('out_len', c_vp), ('out_score', c_vp), ('scratch_alive_pos', c_vp), ('row_parent', c_vp),
-                ('n_alive', c_vp)]
+                ('n_alive', c_vp), ('n_sent_dev', c_vp)]
 
 
 STEP_EMBED, STEP_LAYERS, STEP_VOCAB, STEP_FUSED_CELL = 1, 2, 4, 8
@@ -94,6 +94,8 @@ _PROTOS = {
     'tst_gru_cell_fused_ok': ([c_i64, c_i64], c_int),
     'tst_gru_cell_fused_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_gather_rows_f32': ([c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
+    'tst_scatter_rows_f32': ([c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
+    'tst_pack_sources': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_int),
     'tst_argmax_rows_f32': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_vp], c_int),
     'tst_gumbel_softmax_f32': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_f32, c_vp, c_i64, c_vp], c_int),
     'tst_mix_logprobs_f32': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_vp], c_int),

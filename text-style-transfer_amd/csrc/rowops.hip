@@ -132,6 +132,85 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const float* __restric
 
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
+// dst[idx[r]][:] = src[r][:] (idx without repeats)
+__global__ __launch_bounds__(256) void scatter_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ idx,
+                                                           float* __restrict__ dst, int64_t R, int w4) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= R * w4) return;
+    const int64_t r = i / w4;
+    const int c4 = (int)(i - r * w4);
+    reinterpret_cast<float4*>(dst)[(int64_t)idx[r] * w4 + c4] = reinterpret_cast<const float4*>(src)[i];
+}
+
+// ---- packing of a padded source batch: only the non-padding positions become rows -------------------------------------
+// one wave per sentence: number of non-padding tokens
+__global__ __launch_bounds__(256) void pack_count_kernel(const int64_t* __restrict__ src, int64_t pad, int64_t B, int S,
+                                                         int32_t* __restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    int n = 0;
+    for (int p0 = 0; p0 < S; p0 += 64) {
+        const int p = p0 + lane;
+        n += __popcll(__ballot(p < S && src[b * S + p] != pad));
+    }
+    if (lane == 0) count[b] = n;
+}
+
+// one workgroup: exclusive prefix sum of count[0..B) into offs, total into n_live
+__global__ __launch_bounds__(1024) void pack_scan_kernel(const int32_t* __restrict__ count, int32_t* __restrict__ offs, int64_t B,
+                                                         int32_t* __restrict__ n_live) {
+    __shared__ int wsum[16];
+    const int t = threadIdx.x;
+    const int64_t per = (B + 1023) / 1024;
+    const int64_t lo = (int64_t)t * per, hi = lo + per < B ? lo + per : B;
+    int local = 0;
+    for (int64_t i = lo; i < hi; ++i) local += count[i];
+    int inc = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(inc, off, 64);
+        if ((t & 63) >= off) inc += o;
+    }
+    if ((t & 63) == 63) wsum[t >> 6] = inc;
+    __syncthreads();
+    int wbase = 0;
+    for (int q = 0; q < (t >> 6); ++q) wbase += wsum[q];
+    int run = wbase + inc - local;
+    for (int64_t i = lo; i < hi; ++i) { offs[i] = run; run += count[i]; }
+    if (t == 1023) *n_live = wbase + inc;
+}
+
+// one wave per sentence: mask, row map and the packed rows' token, position, sentence and padded row
+__global__ __launch_bounds__(256) void pack_write_kernel(const int64_t* __restrict__ src, int64_t pad, int64_t B, int S,
+                                                         const int32_t* __restrict__ offs, uint8_t* __restrict__ mask,
+                                                         int32_t* __restrict__ kvrow, int32_t* __restrict__ tok,
+                                                         int32_t* __restrict__ pos, int32_t* __restrict__ sent,
+                                                         int32_t* __restrict__ padded_row) {
+    const int lane = threadIdx.x & 63;
+    const int64_t b = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= B) return;
+    int at = offs[b];
+    for (int p0 = 0; p0 < S; p0 += 64) {
+        const int p = p0 + lane;
+        const int64_t tk = p < S ? src[b * S + p] : pad;
+        const bool live = p < S && tk != pad;
+        const unsigned long long bal = __ballot(live);
+        const int row = at + __popcll(bal & ((1ull << lane) - 1ull));
+        if (p < S) {
+            mask[b * S + p] = live ? 1 : 0;
+            kvrow[b * S + p] = live ? row : -1;
+        }
+        if (live) {
+            tok[row] = (int32_t)tk;
+            pos[row] = p;
+            sent[row] = (int32_t)b;
+            padded_row[row] = (int32_t)(b * S + p);
+        }
+        at += __popcll(bal);
+    }
+}
+
 }  // namespace
 
 extern "C" int tst_embed_posadd_f32(const int32_t* tok, const float* emb, const float* pe, const int32_t* pos, float scale,
@@ -212,4 +291,29 @@ extern "C" int tst_gather_rows_f32(const float* src, const int32_t* idx, float* 
     hipLaunchKernelGGL(gather_rows_kernel, dim3(blocks_for(R * (width / 4), 256)), dim3(256), 0, (hipStream_t)stream, src,
                        idx, dst, R, (int)(width / 4));
     return tst_after_launch("tst_gather_rows_f32");
+}
+
+extern "C" int tst_scatter_rows_f32(const float* src, const int32_t* idx, float* dst, int64_t R, int64_t width, void* stream) {
+    TST_REQUIRE(src && idx && dst && src != dst, TST_ERR_ARG, "tst_scatter_rows_f32: null or aliased pointer");
+    TST_REQUIRE(R >= 0 && width > 0 && width % 4 == 0, TST_ERR_ARG, "tst_scatter_rows_f32: need width %% 4 == 0");
+    TST_REQUIRE(tst_aligned16(src) && tst_aligned16(dst), TST_ERR_ARG, "tst_scatter_rows_f32: alignment");
+    if (R == 0) return TST_OK;
+    hipLaunchKernelGGL(scatter_rows_kernel, dim3(blocks_for(R * (width / 4), 256)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, R,
+                       (int)(width / 4));
+    return tst_after_launch("tst_scatter_rows_f32");
+}
+
+extern "C" int tst_pack_sources(const int64_t* src, int64_t pad, int64_t B, int64_t S, uint8_t* mask, int32_t* kvrow, int32_t* tok,
+                                int32_t* pos, int32_t* sent, int32_t* padded_row, int32_t* work, int32_t* n_live, void* stream) {
+    TST_REQUIRE(src && mask && kvrow && tok && pos && sent && padded_row && work && n_live, TST_ERR_ARG, "tst_pack_sources: null pointer");
+    TST_REQUIRE(B >= 0 && S > 0 && B * S < (1ll << 31), TST_ERR_ARG, "tst_pack_sources: bad sizes");
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* count = work;
+    int32_t* offs = work + B;
+    if (B > 0) hipLaunchKernelGGL(pack_count_kernel, dim3(blocks_for(B, 4)), dim3(256), 0, st, src, pad, B, (int)S, count);
+    hipLaunchKernelGGL(pack_scan_kernel, dim3(1), dim3(1024), 0, st, count, offs, B, n_live);
+    if (B > 0)
+        hipLaunchKernelGGL(pack_write_kernel, dim3(blocks_for(B, 4)), dim3(256), 0, st, src, pad, B, (int)S, offs, mask, kvrow, tok, pos, sent,
+                           padded_row);
+    return tst_after_launch("tst_pack_sources");
 }

@@ -368,9 +368,12 @@ __global__ __launch_bounds__(256) void finish_kernel(tst_rows cur, const int32_t
                                                      const int32_t* __restrict__ fin, const int32_t* __restrict__ nemit,
                                                      const float* __restrict__ lp, int64_t n_sent, int k, int T,
                                                      int last_step, int top_ends, int32_t* out_tok, int32_t* out_len,
-                                                     float* out_score, int32_t* alive) {
+                                                     float* out_score, int32_t* alive, const int32_t* __restrict__ n_true) {
     const int64_t a = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (a >= n_sent) return;
+    // n_sent may be an upper bound (a host that does not wait for the previous step's count): sentences beyond the true
+    // count, kept on the device, do not exist
+    if (n_true != nullptr && a >= *n_true) { alive[a] = 0; return; }
     const int64_t base = a * k;
     bool all_fin = true;
     for (int j = 0; j < k; ++j) all_fin = all_fin && fin[base + j] != 0;
@@ -460,9 +463,10 @@ __global__ __launch_bounds__(1024) void tail_small_kernel(tst_rows cur, tst_rows
                                                           const float* __restrict__ lp, int n_sent, int k, int step, int T,
                                                           int32_t eos, int last_step, int top_ends, int32_t* out_tok,
                                                           int32_t* out_len, float* out_score, int32_t* row_parent,
-                                                          int32_t* n_alive) {
+                                                          int32_t* n_alive, const int32_t* __restrict__ n_true) {
     __shared__ int alive_s[1024], pos_s[1024], wsum[16];
     const int t = threadIdx.x;
+    if (n_true != nullptr) n_sent = min(n_sent, (int)*n_true);   // n_sent may be an upper bound: see finish_kernel
     const int n_rows = n_sent * k;
     if (GREEDY) {   // greedy_select_kernel (k == 1)
         if (t < n_rows) {
@@ -687,7 +691,7 @@ int retire_compact_impl(const tst_rows* cur, const tst_rows* nxt, const int32_t*
                         const float* sel_score, const int32_t* sel_fin, const int32_t* sel_nemit, const float* lp, int64_t n_sent,
                         int64_t k, int64_t step, int64_t T, int32_t eos, int last_step, int top_ends, int32_t* out_tok,
                         int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent, int32_t* n_alive,
-                        void* stream, const char* name) {
+                        void* stream, const char* name, const int32_t* n_true = nullptr) {
     TST_REQUIRE(rows_ok(cur, false) && rows_ok(nxt, cur && cur->anc) && sel_parent && sel_tok && sel_score && sel_fin &&
                     sel_nemit && lp && out_tok && out_len && out_score && scratch_alive_pos && row_parent && n_alive,
                 TST_ERR_ARG, "%s: null pointer", name);
@@ -698,7 +702,7 @@ int retire_compact_impl(const tst_rows* cur, const tst_rows* nxt, const int32_t*
         hipLaunchKernelGGL(tail_small_kernel<false>, dim3(1), dim3(1024), 0, st, *cur, *nxt, nullptr, const_cast<int32_t*>(sel_parent),
                            const_cast<int32_t*>(sel_tok), const_cast<float*>(sel_score), const_cast<int32_t*>(sel_fin),
                            const_cast<int32_t*>(sel_nemit), lp, (int)n_sent, (int)k, (int)step, (int)T, eos, last_step, top_ends,
-                           out_tok, out_len, out_score, row_parent, n_alive);
+                           out_tok, out_len, out_score, row_parent, n_alive, n_true);
         return tst_after_launch(name);
     }
     int32_t* alive = scratch_alive_pos;
@@ -706,7 +710,7 @@ int retire_compact_impl(const tst_rows* cur, const tst_rows* nxt, const int32_t*
     if (n_sent > 0) {
         hipLaunchKernelGGL(finish_kernel, dim3(blocks_for(n_sent, 256)), dim3(256), 0, st, *cur, sel_parent, sel_tok,
                            sel_score, sel_fin, sel_nemit, lp, n_sent, (int)k, (int)T, last_step, top_ends, out_tok, out_len,
-                           out_score, alive);
+                           out_score, alive, n_true);
     }
     hipLaunchKernelGGL(scan_alive_kernel, dim3(1), dim3(1024), 0, st, alive, pos, n_sent, n_alive);
     if (n_sent > 0) {
@@ -777,16 +781,18 @@ extern "C" int tst_retire_compact_noalloc(const tst_rows* cur, const tst_rows* n
                                top_ends, out_tok, out_len, out_score, ptr, row_parent, n_alive, stream, "tst_retire_compact_noalloc");
 }
 
-extern "C" int tst_greedy_retire_compact(const int32_t* argmax_tok, const tst_rows* cur, const tst_rows* nxt, int32_t* sel_parent,
-                                         int32_t* sel_tok, float* sel_score, int32_t* sel_fin, int32_t* sel_nemit, const float* lp,
-                                         int64_t n_sent, int64_t step, int64_t T, int32_t eos, int last_step, int32_t* out_tok,
-                                         int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent,
-                                         int32_t* n_alive, void* stream) {
+namespace {
+
+int greedy_retire_compact_impl(const int32_t* argmax_tok, const tst_rows* cur, const tst_rows* nxt, int32_t* sel_parent, int32_t* sel_tok,
+                               float* sel_score, int32_t* sel_fin, int32_t* sel_nemit, const float* lp, int64_t n_sent, int64_t step,
+                               int64_t T, int32_t eos, int last_step, int32_t* out_tok, int32_t* out_len, float* out_score,
+                               int32_t* scratch_alive_pos, int32_t* row_parent, int32_t* n_alive, void* stream, const int32_t* n_true) {
     if (n_sent > SMALL_TAIL_ROWS || n_sent <= 0) {
         const int rc = tst_greedy_select(argmax_tok, n_sent, eos, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, cur, stream);
         if (rc != TST_OK) return rc;
-        return tst_retire_compact(cur, nxt, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, lp, n_sent, 1, step, T, eos, last_step, 0,
-                                  out_tok, out_len, out_score, scratch_alive_pos, row_parent, n_alive, stream);
+        return retire_compact_impl(cur, nxt, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, lp, n_sent, 1, step, T, eos, last_step, 0,
+                                   out_tok, out_len, out_score, scratch_alive_pos, row_parent, n_alive, stream, "tst_greedy_retire_compact",
+                                   n_true);
     }
     TST_REQUIRE(argmax_tok && rows_ok(cur, false) && rows_ok(nxt, cur && cur->anc) && sel_parent && sel_tok && sel_score && sel_fin &&
                     sel_nemit && lp && out_tok && out_len && out_score && row_parent && n_alive,
@@ -794,6 +800,38 @@ extern "C" int tst_greedy_retire_compact(const int32_t* argmax_tok, const tst_ro
     TST_REQUIRE(step >= 0 && step < T, TST_ERR_ARG, "tst_greedy_retire_compact: bad sizes (need 0 <= step < T)");
     hipLaunchKernelGGL(tail_small_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, *cur, *nxt, argmax_tok, sel_parent, sel_tok,
                        sel_score, sel_fin, sel_nemit, lp, (int)n_sent, 1, (int)step, (int)T, eos, last_step, 0, out_tok, out_len,
-                       out_score, row_parent, n_alive);
+                       out_score, row_parent, n_alive, n_true);
     return tst_after_launch("tst_greedy_retire_compact");
+}
+
+}  // namespace
+
+extern "C" int tst_greedy_retire_compact(const int32_t* argmax_tok, const tst_rows* cur, const tst_rows* nxt, int32_t* sel_parent,
+                                         int32_t* sel_tok, float* sel_score, int32_t* sel_fin, int32_t* sel_nemit, const float* lp,
+                                         int64_t n_sent, int64_t step, int64_t T, int32_t eos, int last_step, int32_t* out_tok,
+                                         int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent,
+                                         int32_t* n_alive, void* stream) {
+    return greedy_retire_compact_impl(argmax_tok, cur, nxt, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, lp, n_sent, step, T, eos,
+                                      last_step, out_tok, out_len, out_score, scratch_alive_pos, row_parent, n_alive, stream, nullptr);
+}
+
+int tst_greedy_retire_compact_bounded(const int32_t* argmax_tok, const tst_rows* cur, const tst_rows* nxt, int32_t* sel_parent,
+                                      int32_t* sel_tok, float* sel_score, int32_t* sel_fin, int32_t* sel_nemit, const float* lp,
+                                      int64_t n_sent, int64_t step, int64_t T, int32_t eos, int last_step, int32_t* out_tok,
+                                      int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent,
+                                      int32_t* n_alive, const int32_t* n_true, void* stream) {
+    return greedy_retire_compact_impl(argmax_tok, cur, nxt, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, lp, n_sent, step, T, eos,
+                                      last_step, out_tok, out_len, out_score, scratch_alive_pos, row_parent, n_alive, stream, n_true);
+}
+
+// The two retirement entry points with the true sentence count read from device memory (n_sent is then an upper bound):
+// used by tst_select_step_run when tst_select_step.n_sent_dev is set.
+int tst_retire_compact_bounded(const tst_rows* cur, const tst_rows* nxt, const int32_t* sel_parent, const int32_t* sel_tok,
+                               const float* sel_score, const int32_t* sel_fin, const int32_t* sel_nemit, const float* lp, int64_t n_sent,
+                               int64_t k, int64_t step, int64_t T, int32_t eos, int last_step, int top_ends, int32_t* out_tok,
+                               int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent, int32_t* n_alive,
+                               const int32_t* n_true, void* stream) {
+    return retire_compact_impl(cur, nxt, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, lp, n_sent, k, step, T, eos, last_step,
+                               top_ends, out_tok, out_len, out_score, scratch_alive_pos, row_parent, n_alive, stream,
+                               "tst_select_step_run", n_true);
 }

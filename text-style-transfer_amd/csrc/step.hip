@@ -193,9 +193,9 @@ extern "C" int tst_select_step_run(const tst_select_step* s, const tst_rows* cur
             TST_TRY(s->bf16_logits ? tst_argmax_rows_bf16(s->logits, s->ld_logits, R, s->V, s->am, stream)
                                    : tst_argmax_rows_f32((const float*)s->logits, s->ld_logits, R, s->V, s->am, stream));
         }
-        return tst_greedy_retire_compact(s->am, cur, nxt, s->sel_parent, s->sel_tok, s->sel_score, s->sel_fin, s->sel_nemit, s->lp, n_sent,
-                                         step, s->T, s->eos, last_step, s->out_tok, s->out_len, s->out_score, s->scratch_alive_pos,
-                                         s->row_parent, s->n_alive, stream);
+        return tst_greedy_retire_compact_bounded(s->am, cur, nxt, s->sel_parent, s->sel_tok, s->sel_score, s->sel_fin, s->sel_nemit, s->lp,
+                                                 n_sent, step, s->T, s->eos, last_step, s->out_tok, s->out_len, s->out_score,
+                                                 s->scratch_alive_pos, s->row_parent, s->n_alive, s->n_sent_dev, stream);
     } else {
         TST_TRY(s->bf16_logits ? tst_logsoftmax_topk_bf16(s->logits, s->ld_logits, R, s->V, s->k, s->top_val, s->top_idx, s->lse, stream)
                                : tst_logsoftmax_topk_f32((const float*)s->logits, s->ld_logits, R, s->V, s->k, s->top_val, s->top_idx,
@@ -203,7 +203,7 @@ extern "C" int tst_select_step_run(const tst_select_step* s, const tst_rows* cur
         TST_TRY(tst_beam_merge(cur, s->top_val, s->top_idx, s->lse, n_sent, s->k, k_in, s->eos, s->sel_parent, s->sel_tok, s->sel_score,
                                s->sel_fin, s->sel_nemit, stream));
     }
-    return tst_retire_compact(cur, nxt, s->sel_parent, s->sel_tok, s->sel_score, s->sel_fin, s->sel_nemit, s->lp, n_sent, s->k, step, s->T,
-                              s->eos, last_step, s->top_ends, s->out_tok, s->out_len, s->out_score, s->scratch_alive_pos, s->row_parent,
-                              s->n_alive, stream);
+    return tst_retire_compact_bounded(cur, nxt, s->sel_parent, s->sel_tok, s->sel_score, s->sel_fin, s->sel_nemit, s->lp, n_sent, s->k, step,
+                                      s->T, s->eos, last_step, s->top_ends, s->out_tok, s->out_len, s->out_score, s->scratch_alive_pos,
+                                      s->row_parent, s->n_alive, s->n_sent_dev, stream);
 }

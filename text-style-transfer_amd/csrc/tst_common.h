@@ -9,6 +9,18 @@
 
 void tst_set_error(const char* fmt, ...);
 
+// select.hip: the retirement entry points with the true sentence count read from device memory (n_sent an upper bound)
+int tst_retire_compact_bounded(const tst_rows* cur, const tst_rows* nxt, const int32_t* sel_parent, const int32_t* sel_tok,
+                               const float* sel_score, const int32_t* sel_fin, const int32_t* sel_nemit, const float* lp, int64_t n_sent,
+                               int64_t k, int64_t step, int64_t T, int32_t eos, int last_step, int top_ends, int32_t* out_tok,
+                               int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent, int32_t* n_alive,
+                               const int32_t* n_true, void* stream);
+int tst_greedy_retire_compact_bounded(const int32_t* argmax_tok, const tst_rows* cur, const tst_rows* nxt, int32_t* sel_parent,
+                                      int32_t* sel_tok, float* sel_score, int32_t* sel_fin, int32_t* sel_nemit, const float* lp,
+                                      int64_t n_sent, int64_t step, int64_t T, int32_t eos, int last_step, int32_t* out_tok,
+                                      int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent,
+                                      int32_t* n_alive, const int32_t* n_true, void* stream);
+
 // attn_mfma.hip: the matrix-core cross-attention of beam groups (used by tst_attn_cross_group_f32)
 int tst_cross_mfma_ok(int64_t S, int64_t dh, int64_t group);
 int tst_launch_cross_mfma(const float* kv, const int32_t* kvrow, const float* q, const uint8_t* mask, const int32_t* sent, int64_t S,

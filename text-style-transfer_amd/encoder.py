@@ -69,19 +69,14 @@ class TransformerEncoder(HipModule):
         B, S = src.shape
         if S > W['pe'].shape[0]:
             raise ValueError('source length %d exceeds pe_max_len %d' % (S, W['pe'].shape[0]))
-        enc_mask = (src != self.pad_idx)
-        flat = enc_mask.reshape(-1)
-        idx = flat.nonzero().squeeze(1)                       # packed row -> padded row, ascending
-        n = int(idx.numel())
         f32 = dict(dtype=torch.float32, device=dev)
+        packed = K.PackedSources(src.to(torch.int64).contiguous(), self.pad_idx)    # one kernel sequence, one host read
+        n = packed.n
+        enc_mask = packed.mask.view(B, 1, S).to(torch.bool)
         encs = torch.zeros((B * S, d), **f32)
         if n == 0:
-            return encs.view(B, S, d), enc_mask.unsqueeze(1)
-        mask8 = enc_mask.to(torch.uint8).contiguous()
-        kvrow = (torch.cumsum(flat, 0, dtype=torch.int32) - 1).view(B, S).contiguous()   # padded row -> packed row
-        tok = src.reshape(-1)[idx].to(torch.int32)
-        pos = (idx % S).to(torch.int32)
-        sent = (idx // S).to(torch.int32)
+            return encs.view(B, S, d), enc_mask
+        mask8, kvrow, tok, pos, sent = packed.mask, packed.kvrow, packed.tok, packed.pos, packed.sent
         x = torch.empty((n, d), **f32)
         h, q, a = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
         kv = torch.empty((n, 2 * d), **f32)
@@ -98,5 +93,10 @@ class TransformerEncoder(HipModule):
             K.gemm(h, L['w1'], L['b1'], ff, n, act=1)
             K.gemm(ff, L['w2'], L['b2'], x, n, res=x)
         K.layernorm(x, W['ln'][0], W['ln'][1], h, n)
-        encs.index_copy_(0, idx, h)
-        return encs.view(B, S, d), enc_mask.unsqueeze(1)
+        K.scatter_rows(h, packed.padded_row, encs, n)
+        encs = encs.view(B, S, d)
+        # the decoder session of this package can take the packed rows as they are (no second packing pass) when it is handed
+        # these two tensor objects unchanged
+        packed.rows = h
+        encs._tst_packed = enc_mask._tst_packed = packed
+        return encs, enc_mask

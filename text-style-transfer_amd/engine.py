@@ -48,6 +48,21 @@ def _lp_on_device(max_len, alpha, dev):
     return _LP_CACHE[key]
 
 
+LAG_MAX_ROWS = 0 if __import__('os').environ.get('TST_NO_LAG') else 2048   # sentences x beams up to which the loop does not wait for a step's survivor count before the next launch
+
+
+_PINNED = {}
+
+
+def _pinned_counts(dev):
+    """Two int32 of page-locked host memory per device for the late reads of the survivor counts (allocating page-locked
+    memory per decode call would cost more than the reads save).  One decode loop runs at a time per host thread and device."""
+    key = (str(dev), __import__('threading').get_ident())
+    if key not in _PINNED:
+        _PINNED[key] = torch.zeros(2, dtype=torch.int32).pin_memory()
+    return _PINNED[key]
+
+
 class DecodeLoop:
     def __init__(self, session, n_sent, beam, max_len, bos, eos, pad, alpha=0.0, device=None, sample=None, gumbel=None,
                  prefix=None):
@@ -91,9 +106,14 @@ class DecodeLoop:
         i32 = dict(dtype=torch.int32, device=dev)
         self.out_tok = torch.full((n_sent, self.Ttot + 1), pad, **i32)
         self.out_score = torch.zeros(n_sent, dtype=torch.float32, device=dev)
-        shapes = [(n_sent,), (2 * n_sent,), (R,), (1,), (R,)]      # one allocation for the small int32 arrays
+        shapes = [(n_sent,), (2 * n_sent,), (R,), (1,), (R,), (1,)]      # one allocation for the small int32 arrays
         arena = torch.zeros(K._arena_size(shapes), **i32)
-        self.out_len, self.scratch, self.row_parent, self.n_alive, self.am = K._carve(arena, shapes)
+        self.out_len, self.scratch, self.row_parent, self.n_alive, self.am, self.n_alive_b = K._carve(arena, shapes)
+        # Small batches are bound by the chain of dependent launches, and a blocking read of the survivor count after every
+        # step adds a round trip to it.  There the loop launches step t + 1 with the count it read after step t - 1 (an upper
+        # bound: counts only fall), the kernels take the true count from device memory, and the host reads counts one step
+        # late from pinned memory.  Large batches keep the exact count (extra rows would cost real time there).
+        self.lagged = (R <= LAG_MAX_ROWS and gumbel is None and getattr(session, 'lag_ok', False))
         self.top_val = self.top_idx = self.lse = None
         if beam > 1:
             self.top_val = torch.zeros((R, beam), dtype=torch.float32, device=dev)
@@ -135,6 +155,8 @@ class DecodeLoop:
                 self.cur.tok[:n_sent] = self.prefix[:, p]
                 s.step(self.cur, n_sent, p)
             self.cur.tok[:n_sent] = self.prefix[:, -1]
+        if self.lagged and self.select_log is None:
+            return self._run_lagged(keep_logits)
         for t in range(T):
             k_in = 1 if t == 0 else k      # rows per sentence going into this step
             R = n_sent * k_in
@@ -186,4 +208,56 @@ class DecodeLoop:
             if self.gumbel is not None:
                 K.gather_rows(self.dist_out, self.row_parent, self.dist_in, alive)
             n_sent = alive
+        return self.out_tok, self.out_len, self.out_score
+
+    def _run_lagged(self, keep_logits):
+        """The loop without a blocking read per step (see ``self.lagged``): same kernels, same results; a finished batch is
+        noticed one step late (that step runs on zero sentences)."""
+        s, k, T = self.s, self.k, self.T
+        pos0, Ttot = self.pos0, self.Ttot
+        counts = (self.n_alive, self.n_alive_b)                     # device: survivors of step t in counts[t % 2]
+        host = _pinned_counts(self.dev)
+        events = (torch.cuda.Event(), torch.cuda.Event())
+        bound = self.B                                              # upper bound of the sentences entering the coming step
+        for t in range(T):
+            k_in = 1 if t == 0 else k
+            R = bound * k_in
+            s.rows_per_sentence = k_in
+            logits = s.step(self.cur, R, pos0 + t)
+            if t < keep_logits:
+                self.kept.append((logits[:R, :s.V].clone(), self.cur.sent[:R].clone(), self.cur.fin[:R].clone()))
+            if self.tail is None:
+                _check_logits(logits, R, s.V)
+                self.tail = K.SelectPlan(k=k, eos=self.eos, V=s.V, logits=logits, am=self.am, top_val=self.top_val,
+                                         top_idx=self.top_idx, lse=self.lse, sel=self.sel, lp=self.lp, T=Ttot,
+                                         top_ends=self.top_ends, sample=self.sample, out_tok=self.out_tok, out_len=self.out_len,
+                                         out_score=self.out_score, scratch=self.scratch, row_parent=self.row_parent,
+                                         n_alive=self.n_alive)
+            elif logits.data_ptr() != self.tail.logits_ptr:
+                _check_logits(logits, R, s.V)
+                self.tail.set_logits(logits)
+            self.tail.set_counts(counts[t % 2], counts[(t - 1) % 2] if t > 0 else None)
+            self.tail.run(self.cur, self.nxt, bound, k_in, pos0 + t, t, t == T - 1)
+            host[t % 2:t % 2 + 1].copy_(counts[t % 2], non_blocking=True)
+            events[t % 2].record()
+            self.cur, self.nxt = self.nxt, self.cur
+            self.steps_done += 1
+            self.rows_stepped += R
+            if t == 0:                                  # every sentence entered step 0: the bound is exact
+                s.reorder(self.row_parent, bound * k, identity=False)
+                continue
+            events[(t - 1) % 2].synchronize()           # the count after step t - 1: that step ended before step t began
+            entering = int(host[(t - 1) % 2])           # = sentences that entered step t >= those that enter step t + 1
+            if keep_logits and entering < bound:        # the kept rows of step t beyond the true count were stale
+                lg, sent, fin = self.kept[-1] if t < keep_logits else (None, None, None)
+                if lg is not None:
+                    self.kept[-1] = (lg[:entering * k_in], sent[:entering * k_in], fin[:entering * k_in])
+            if entering == 0:                           # step t ran on no sentence at all
+                self.steps_done -= 1
+                self.rows_stepped -= R
+                if t < keep_logits:
+                    self.kept.pop()
+                break
+            s.reorder(self.row_parent, entering * k, identity=False)
+            bound = entering
         return self.out_tok, self.out_len, self.out_score

@@ -230,6 +230,33 @@ def gather_rows(src, idx, dst, n_rows):
     call('tst_gather_rows_f32', _p(src), _p(idx), _p(dst), n_rows, src.shape[1], _stream())
 
 
+def scatter_rows(src, idx, dst, n_rows):
+    """dst[idx[r]] = src[r] for r < n_rows"""
+    _chk(src, torch.float32, 'src'); _chk(dst, torch.float32, 'dst'); _chk(idx, torch.int32, 'idx')
+    assert src.shape[1] == dst.shape[1]
+    call('tst_scatter_rows_f32', _p(src), _p(idx), _p(dst), n_rows, src.shape[1], _stream())
+
+
+class PackedSources:
+    """The non-padding positions of a source batch [B, S] as packed rows (``tst_pack_sources``): ``mask`` [B, S] uint8,
+    ``kvrow`` [B, S] int32, and per packed row ``tok``, ``pos``, ``sent``, ``padded_row`` (first ``n`` entries valid).  One
+    device-to-host read (the number of tokens)."""
+
+    def __init__(self, src, pad):
+        if not (src.is_cuda and src.dtype == torch.int64 and src.dim() == 2 and src.is_contiguous()):
+            raise ValueError('src must be a contiguous int64 [B, S] tensor on the GPU')
+        B, S = src.shape
+        dev = src.device
+        self.B, self.S = B, S
+        self.mask = torch.empty((B, S), dtype=torch.uint8, device=dev)
+        shapes = [(B, S), (B * S,), (B * S,), (B * S,), (B * S,), (2 * B,), (1,)]
+        arena = torch.empty(_arena_size(shapes), dtype=torch.int32, device=dev)
+        self.kvrow, self.tok, self.pos, self.sent, self.padded_row, work, n_live = _carve(arena, shapes)
+        call('tst_pack_sources', _p(src), int(pad), B, S, _p(self.mask), _p(self.kvrow), _p(self.tok), _p(self.pos), _p(self.sent),
+             _p(self.padded_row), _p(work), _p(n_live), _stream())
+        self.n = int(n_live.item())
+
+
 def _logits_suffix(logits):
     if not (logits.is_cuda and logits.dtype in (torch.float32, torch.bfloat16) and logits.stride(-1) == 1):
         raise ValueError('logits must be an fp32 or bf16 GPU tensor with unit inner stride')
@@ -326,7 +353,7 @@ class SelectPlan:
             sel_fin=sp[3], sel_nemit=sp[4], lp=_p(lp), T=T, top_ends=int(top_ends), sample=int(sample is not None),
             temperature=float(sample[0]) if sample is not None else 1.0, seed=(int(sample[1]) & 0xffffffff) if sample is not None else 0,
             out_tok=_p(out_tok), out_len=_p(out_len), out_score=_p(out_score), scratch_alive_pos=_p(scratch),
-            row_parent=_p(row_parent), n_alive=_p(n_alive))
+            row_parent=_p(row_parent), n_alive=_p(n_alive), n_sent_dev=None)
         self.logits_ptr = _p(logits)
 
     def set_logits(self, logits):
@@ -335,6 +362,12 @@ class SelectPlan:
         self._keep[0] = logits
         self.c.logits, self.c.ld_logits, self.c.bf16_logits = _p(logits), logits.stride(0), int(logits.dtype == torch.bfloat16)
         self.logits_ptr = _p(logits)
+
+    def set_counts(self, n_alive, n_sent_dev):
+        """Where the step writes the number of surviving sentences, and (or None) where the true number of sentences
+        entering the step is read from when ``n_sent`` of ``run`` is an upper bound."""
+        self._keep_counts = (n_alive, n_sent_dev)
+        self.c.n_alive, self.c.n_sent_dev = _p(n_alive), _p(n_sent_dev)
 
     def run(self, cur, nxt, n_sent, k_in, step, sample_step, last_step):
         call('tst_select_step_run', self.c, cur.struct(), nxt.struct(), n_sent, k_in, step, sample_step, int(last_step), _stream())

@@ -163,6 +163,7 @@ class TransformerLMSession:
     needs_anc = True
     incremental = True
     takes_soft = True
+    lag_ok = True     # rows beyond the true count may be stepped on stale state without harm (engine.DecodeLoop.lagged)
 
     def __init__(self, lm, z, k, max_len):
         self.lm, self.V = lm, lm.V

@@ -166,6 +166,7 @@ class GRUSession:
     needs_anc = False
     takes_soft = True
     incremental = True
+    lag_ok = True     # rows beyond the true count may be stepped on stale state without harm (engine.DecodeLoop.lagged)
 
     def __init__(self, model, z, k, extra=None):
         self.m, self.V = model, model.V
@@ -276,6 +277,7 @@ class WeightedLMEnsemble:
 class EnsembleSession:
     needs_anc = False
     incremental = True
+    lag_ok = True
 
     def __init__(self, ens, zs, k, max_len):
         self.ens, self.V = ens, ens.V

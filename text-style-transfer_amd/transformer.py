@@ -220,6 +220,7 @@ class TransformerSession:
     needs_anc = True
     takes_soft = True
     incremental = True
+    lag_ok = True     # rows beyond the true count may be stepped on stale state without harm (engine.DecodeLoop.lagged)
 
     def __init__(self, dec, encs, enc_mask, k, max_len):
         self.dec, self.V = dec, dec.V
@@ -227,6 +228,9 @@ class TransformerSession:
         dev = dec.device
         if max_len > W['pe'].shape[0]:
             raise ValueError('max_len %d exceeds pe_max_len %d' % (max_len, W['pe'].shape[0]))
+        packed = getattr(encs, '_tst_packed', None)
+        if packed is None or packed is not getattr(enc_mask, '_tst_packed', None) or packed.rows.device != dev:
+            packed = None     # not the untouched outputs of this package's encoder: pack here
         encs = encs.to(device=dev, dtype=torch.float32).contiguous()
         B, S, d = encs.shape
         if d != dec.d:
@@ -234,14 +238,17 @@ class TransformerSession:
         self.B, self.S, self.k = B, S, k
         R = B * k
         self.R = R
-        self.mask = _normalise_mask(enc_mask, B, S, dev)
+        self.mask = packed.mask if packed is not None else _normalise_mask(enc_mask, B, S, dev)
         f32 = dict(dtype=torch.float32, device=dev)
         flat = encs.view(B * S, d)
         # k|v of the encoder outputs, for the non-padding source positions only: rows packed sentence after sentence,
         # kvrow[sentence, position] = packed row (a batch padded to its longest sentence is mostly padding)
         self.kvrow = None
         n_src = B * S
-        if self.mask is not None:
+        if packed is not None:
+            if 0 < packed.n < B * S:
+                self.kvrow, flat, n_src = packed.kvrow, packed.rows, packed.n
+        elif self.mask is not None:
             live = self.mask.view(-1) != 0
             idx = live.nonzero().squeeze(1)
             if 0 < idx.numel() < B * S:
