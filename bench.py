@@ -44,7 +44,7 @@ OUT_SCALE = 2.0
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak of MI355X
 BF16_MATRIX_PEAK_TFLOPS = 2500.0
 HBM_PEAK_GBS = 8000.0            # HBM3E peak of MI355X
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r01_vocab_gemm_traffic.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r02_vocab_gemm_traffic.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 PEAKS_BIN = os.path.join(ROOT, 'tools', 'peaks')
 
 
@@ -362,7 +362,8 @@ def main():
                 'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / FP32_MATRIX_PEAK_TFLOPS, 'traffic': traffic,
                 'traffic_source': 'rocprofv3 --pmc passes of this command, committed under profiles/ (not collected in this run)',
-                'kernel': 'gemm_f32_kernel (vocabulary projection [rows,256]x[256,32000], fp32 MFMA)',
+                'kernel': 'gemm_f32_dma_kernel (vocabulary projection [rows,256]x[256,32000], fp32 MFMA, operands by LDS-DMA; '
+                          'gemm_f32_kernel for launches under 2048 rows)',
                 'launches': gemm_launches, 'avg_launch_ms': gemm_ms / max(1, gemm_launches),
                 'share_of_batch_time': gemm_ms / batch_ms,
                 'pass': 'separate event-timed pass over one batch after the timed region (HIP events on the launch stream)'}
