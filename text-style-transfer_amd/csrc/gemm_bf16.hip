@@ -225,9 +225,12 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_bf16_dma_kernel(const __b
     const int bid = blockIdx.x;
     const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
     const int lb = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
-    const int per_group = GROUP_M * tiles_n;
-    const int first_m = (lb / per_group) * GROUP_M;
-    const int gsz = min(tiles_m - first_m, GROUP_M);
+    // m-group of the tile order: the 32 tiles an XCD works on at a time are GM x (32 / GM); with 256-row tiles 8 x 4 keeps
+    // both operand panels (2 MB + 1 MB at K = 512) in the XCD's 4 MB L2 next to the lines being written
+    constexpr int GM = TM >= 256 ? 8 : GROUP_M;
+    const int per_group = GM * tiles_n;
+    const int first_m = (lb / per_group) * GM;
+    const int gsz = min(tiles_m - first_m, GM);
     const int tm = first_m + (lb % per_group) % gsz;
     const int tn = (lb % per_group) / gsz;
     const int m0 = tm * TM, n0 = tn * TN;
@@ -421,7 +424,11 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_bf16_dma_kernel(const __b
                 const uint4 o = *reinterpret_cast<const uint4*>(img + lrow * OUT_LD + c8 * 2);
                 __bf16* cp = reinterpret_cast<__bf16*>(Cout) + (int64_t)grow * ldc + gcol;
                 if (gcol + 8 <= N) {
-                    *reinterpret_cast<uint4*>(cp) = o;
+                    // nontemporal: a wide bf16 result (the logits) is read again only after it has left the caches, and
+                    // written back through the L2 it pushes the operand panels out (measured +20 % on the projection)
+                    u32x4 ov;
+                    ov[0] = o.x; ov[1] = o.y; ov[2] = o.z; ov[3] = o.w;
+                    __builtin_nontemporal_store(ov, reinterpret_cast<u32x4*>(cp));
                 } else {
                     Chunk oc;
                     oc.u = o;
@@ -431,6 +438,233 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_bf16_dma_kernel(const __b
             }
         }
     }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------
+// Persistent form of the 256 x 256 tile for bf16 results without a residual (vocabulary projection, q|k|v, ff1):
+// one workgroup per CU walks the tiles slot, slot + 32, ... of its XCD's contiguous range.  When the last k-step of
+// a tile has been read, the first NST stages of the NEXT tile (and its 1 KiB of bias, also by LDS-DMA) are requested
+// before the epilogue starts, so the epilogue runs under that latency, and the epilogue's stores drain under the next
+// tile's k loop: they are nontemporal (4 GB of logits per launch would otherwise push the operand panels out of the
+// L2) and nothing waits for them before k-tile NST - 1 of the next tile.  Vector-memory operations of a wave complete
+// in issue order, so the counted waits below count the stores that were issued between the DMA they wait for and now;
+// after a partial tile (fewer stores than NSTORE) the stricter count without stores is used.
+// The bf16 image of the epilogue is a region of its own behind the stages (32 rows per wave at a time), written
+// and read with inline assembly: LDS accesses the compiler knows of would be ordered behind every pending DMA.
+template <int NST, bool RELU>
+__global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(const __bf16* __restrict__ A, int64_t lda,
+                                                                const __bf16* __restrict__ W, int64_t ldw,
+                                                                const float* __restrict__ bias, __bf16* __restrict__ Cout,
+                                                                int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr int WVN = 4, WTM = 4, WTN = 2, NWV = 8, TM = 256, TN = 256, GM = 8;
+    constexpr int STAGE = (TM + TN) * 64;
+    constexpr int OUT_LD = 16 + 64 * WTN;                // bytes per row of a wave's output image
+    constexpr int IMG = 32 * OUT_LD;                     // 32 rows at a time
+    constexpr int BIAS_OFF = NST * STAGE, IMG_OFF = BIAS_OFF + NWV * 1024;
+    constexpr int NA = TM / (16 * NWV), NW = TN / (16 * NWV), NDMA = NA + NW;
+    constexpr int NSTORE = WTM * 4;                      // global stores of a wave per full tile
+    static_assert(NDMA * (NST - 1) + NSTORE < 64, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[IMG_OFF + NWV * IMG];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WVN, wn = wave % WVN;
+    const int h = lane >> 5, srow = lane >> 2;
+    const int nkt = K / DK;                              // >= NST (checked by the launcher)
+
+    // this workgroup's tiles: XCD (bid & 7) owns a contiguous range of the m-grouped tile order, slot bid >> 3 of
+    // gridDim.x / 8 takes every (gridDim.x / 8)-th tile of it
+    const int nwg = tiles_m * tiles_n, bid = blockIdx.x, slots = gridDim.x >> 3;
+    const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
+    const int lb_begin = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    const int lb_end = lb_begin + q + (xcd < rem ? 1 : 0);
+    int lb = lb_begin + (bid >> 3);
+    if (lb >= lb_end) return;                            // workgroup-uniform
+
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    int m0, n0;
+    const __bf16* a_src[NA];
+    const __bf16* w_src[NW];
+    auto locate = [&](int l) {
+        const int per_group = GM * tiles_n;
+        const int first_m = (l / per_group) * GM;
+        const int gsz = min(tiles_m - first_m, GM);
+        m0 = (first_m + (l % per_group) % gsz) * TM;
+        n0 = ((l % per_group) / gsz) * TN;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const int row = (wave + NWV * j) * 16 + srow;
+            a_src[j] = A + (int64_t)min(m0 + row, M - 1) * lda + (((lane & 3) ^ ((row >> 2) & 3)) * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int row = (wave + NWV * j) * 16 + srow;
+            w_src[j] = W + (int64_t)min(n0 + row, N - 1) * ldw + (((lane & 3) ^ ((row >> 2) & 3)) * 8);
+        }
+    };
+    auto stage = [&](int st, int k0) {
+        unsigned char* base = smem + st * STAGE + wave * 1024;
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src[j] + k0), (lds_void_t*)(base + j * (1024 * NWV)), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NW; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(w_src[j] + k0), (lds_void_t*)(base + TM * 64 + j * (1024 * NWV)), 16, 0, 0);
+    };
+    // every wave fetches the 256 bias values of the tile into a slot of its own (one more DMA, the oldest of the group)
+    auto request_tile = [&]() {
+        if (bias != nullptr)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(bias + min(n0 + 4 * lane, N - 4)), (lds_void_t*)(smem + BIAS_OFF + wave * 1024), 16, 0, 0);
+#pragma unroll
+        for (int p = 0; p < NST; ++p) stage(p, p * DK);
+    };
+
+    const int x = ((lane & 31) >> 2) & 3;
+    const uint32_t a_off = lds_base + wm * 32 * WTM * 64 + (lane & 31) * 64;
+    const uint32_t w_off = lds_base + TM * 64 + wn * 32 * WTN * 64 + (lane & 31) * 64;
+    union Frag { u32x4 u; bf16x8 v; };
+    Frag fa[2][WTM], fw[2][WTN];
+    f32x16 acc[WTM][WTN];
+    auto read_step = [&](int st, int ks) {
+        const uint32_t as = a_off + st * STAGE, ws = w_off + st * STAGE;
+        const uint32_t slot = ((2 * ks + h) ^ x) * 16;
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[ks][i].u) : "v"(as + i * 2048 + slot));
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(fw[ks][j].u) : "v"(ws + j * 2048 + slot));
+    };
+    auto mfma_step = [&](int ks) {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[ks][j].v, fa[ks][i].v, acc[i][j], 0, 0, 0);
+    };
+    auto lds_wait = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    locate(lb);
+    request_tile();
+    bool stores_behind = false;     // NSTORE stores were issued after the DMA group the next waits refer to
+    while (true) {
+        // stage 0 (and the bias, which is older) landed
+        if (stores_behind) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NST - 1) + NSTORE) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NST - 1)) : "memory");
+        // accumulators from the wave's own bias slot: acc[i][j][4 g + e] belongs to column 32 j + 8 g + 4 h + e of the wave's 64
+        if (bias != nullptr) {
+            const uint32_t bo = lds_base + BIAS_OFF + wave * 1024 + (wn * 64 + 4 * h) * 4;
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) {
+                u32x4 bq[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) asm volatile("ds_read_b128 %0, %1" : "=v"(bq[g]) : "v"(bo + (j * 32 + 8 * g) * 4));
+                lds_wait();
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float b = __uint_as_float(bq[g][e]);
+#pragma unroll
+                        for (int i = 0; i < WTM; ++i) acc[i][j][4 * g + e] = b;
+                    }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                for (int j = 0; j < WTN; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+        }
+        __builtin_amdgcn_s_barrier();
+        read_step(0, 0);
+        int st = 0;
+        for (int kt = 0; kt < nkt; ++kt) {
+            const int st_next = st + 1 == NST ? 0 : st + 1;
+            lds_wait();
+            read_step(st, 1);
+            mfma_step(0);
+            if (kt + NST - 1 < nkt) {
+                if (stores_behind && kt < NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NST - 2) + NSTORE) : "memory");
+                else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NST - 2)) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            }
+            lds_wait();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (kt + NST < nkt) stage(st, (kt + NST) * DK);
+            if (kt + 1 < nkt) read_step(st_next, 0);
+            mfma_step(1);
+            st = st_next;
+        }
+        __builtin_amdgcn_s_barrier();   // every wave is past its last fragment read: the stages are free
+
+        const int tm0 = m0, tn0 = n0;
+        lb += slots;
+        const bool more = lb < lb_end;
+        if (more) {
+            locate(lb);
+            request_tile();
+        }
+
+        // epilogue of tile (tm0, tn0): per 32-row block the lane packs its 2 x 16 results to bf16 into the wave's image
+        // (row = lane & 31), then 8 lanes read one 128-byte row segment back and store it
+        const bool full = tm0 + TM <= M && tn0 + TN <= N;
+        const uint32_t img = lds_base + IMG_OFF + wave * IMG;
+        const uint32_t wr = img + (lane & 31) * OUT_LD + 8 * h;
+        const uint32_t rd = img + (lane >> 3) * OUT_LD + (lane & 7) * 16;
+        const int gcol = tn0 + wn * 64 + (lane & 7) * 8;
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) {
+#pragma unroll
+            for (int j = 0; j < WTN; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    union { bf16x4 b; uint2 u; } cv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        float v = acc[i][j][4 * g + e];
+                        if (RELU) v = v > 0.0f ? v : 0.0f;
+                        cv.b[e] = (__bf16)v;
+                    }
+                    asm volatile("ds_write_b64 %0, %1" ::"v"(wr + j * 64 + 16 * g), "v"(cv.u) : "memory");
+                }
+            u32x4 o[4];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) asm volatile("ds_read_b128 %0, %1" : "=v"(o[p]) : "v"(rd + p * 8 * OUT_LD) : "memory");
+            lds_wait();
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int grow = tm0 + wm * 128 + i * 32 + p * 8 + (lane >> 3);
+                __bf16* cp = Cout + (int64_t)grow * ldc + gcol;
+                if (full) {
+                    __builtin_nontemporal_store(o[p], reinterpret_cast<u32x4*>(cp));
+                } else if (grow < M && gcol < N) {
+                    if (gcol + 8 <= N) {
+                        __builtin_nontemporal_store(o[p], reinterpret_cast<u32x4*>(cp));
+                    } else {
+                        Frag oc;
+                        oc.u = o[p];
+                        for (int e = 0; e < 8; ++e)
+                            if (gcol + e < N) cp[e] = oc.v[e];
+                    }
+                }
+            }
+        }
+        if (!more) break;
+        stores_behind = full;
+    }
+}
+
+// TST_BF16_NO_PERSIST=1 in the environment selects the one-tile-per-workgroup kernel (measurements)
+bool tst_bf16_no_persist() {
+    static const bool v = [] { const char* e = getenv("TST_BF16_NO_PERSIST"); return e != nullptr && e[0] == '1'; }();
+    return v;
 }
 
 }  // namespace
@@ -457,6 +691,17 @@ extern "C" int tst_gemm_mfma_bf16(const void* A, int64_t lda, const void* W, int
         const int64_t tm = big ? (M + 255) / 256 : (M + 127) / 128, tn = big ? (N + 255) / 256 : (N + 127) / 128;
         TST_REQUIRE(tm * tn < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_bf16: grid too large");
         const dim3 g2((unsigned)(tm * tn));
+        if (big && out_bf16 && res == nullptr && K / DK >= 3 && !tst_bf16_no_persist()) {
+            // one workgroup per CU (the kernel's LDS allows no second one), a multiple of 8 so that every XCD has the same slots
+            const dim3 gp(256);
+            if (act == 1)
+                hipLaunchKernelGGL((gemm_bf16_persist_kernel<3, true>), gp, dim3(512), 0, st, (const __bf16*)A, lda, (const __bf16*)W, ldw,
+                                   bias, (__bf16*)C, ldc, (int)M, (int)N, (int)K, (int)tm, (int)tn);
+            else
+                hipLaunchKernelGGL((gemm_bf16_persist_kernel<3, false>), gp, dim3(512), 0, st, (const __bf16*)A, lda, (const __bf16*)W, ldw,
+                                   bias, (__bf16*)C, ldc, (int)M, (int)N, (int)K, (int)tm, (int)tn);
+            return tst_after_launch("tst_gemm_mfma_bf16");
+        }
 #define TST_BF16_DMA(OB, HR, RL)                                                                                      \
     do {                                                                                                              \
         if (big)                                                                                                      \

@@ -26,7 +26,7 @@ constexpr int TN = 256, GROUP_M = 16;
 // short-K and close to the memory roofline: a row moves 3 KB per 131 kFLOP): not instantiated.
 // OUT_T: the product is computed transposed (operands swapped: the same fma chain per element), a lane then owns a ROW
 // and its 16 registers are 16 columns, and C (and res) are K-MAJOR, C[n][m]: 32 lanes store 128 contiguous bytes.
-template <int TM, int WVM, int WVN, int BK, int NST, bool HAS_RES, bool RELU, bool OUT_T>
+template <int TM, int WVM, int WVN, int BK, int NST, bool HAS_RES, bool RELU, bool OUT_T, bool NT_STORE = false>
 __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __restrict__ AT, int64_t ldat, const float* __restrict__ W,
                                                               int64_t ldw, const float* __restrict__ bias, const float* res, int64_t ldr,
                                                               float* C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
@@ -198,7 +198,10 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __res
                     float v = acc[i][j][r];
                     if (RELU) v = v > 0.0f ? v : 0.0f;
                     if (HAS_RES) v = v + rv[r];
-                    if (full_tile || (col < N && row < M)) C[(int64_t)row * ldc + col] = v;
+                    if (full_tile || (col < N && row < M)) {
+                        if (NT_STORE) __builtin_nontemporal_store(v, &C[(int64_t)row * ldc + col]);
+                        else C[(int64_t)row * ldc + col] = v;
+                    }
                 }
             }
         }
@@ -268,11 +271,11 @@ extern "C" int tst_layernorm_t_f32(const float* x, const float* gamma, const flo
 
 namespace {
 
-template <int BK, int NST>
+template <int BK, int NST, bool NT_STORE = false>
 void launch_plain128(const float* AT, int64_t ldat, const float* Wt, int64_t ldw, const float* bias, float* C, int64_t ldc, int64_t M,
                      int64_t N, int64_t K, hipStream_t st) {
     const int64_t tiles_m = (M + 127) / 128, tiles_n = (N + TN - 1) / TN;
-    hipLaunchKernelGGL((gemm_f32_dma_kernel<128, 2, 2, BK, NST, false, false, false>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st,
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<128, 2, 2, BK, NST, false, false, false, NT_STORE>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, st,
                        AT, ldat, Wt, ldw, bias, nullptr, 0, C, ldc, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n);
 }
 
@@ -293,6 +296,7 @@ extern "C" int tst_gemm_dma_f32(const float* AT, int64_t ldat, const float* Wt, 
     switch (variant) {
         case 1: launch_plain128<8, 4>(AT, ldat, Wt, ldw, bias, C, ldc, M, N, K, st); break;
         case 0: launch_plain128<16, 3>(AT, ldat, Wt, ldw, bias, C, ldc, M, N, K, st); break;
+        case 3: launch_plain128<8, 6, true>(AT, ldat, Wt, ldw, bias, C, ldc, M, N, K, st); break;
         default: launch_plain128<8, 6>(AT, ldat, Wt, ldw, bias, C, ldc, M, N, K, st); break;
     }
     return tst_after_launch("tst_gemm_dma_f32");

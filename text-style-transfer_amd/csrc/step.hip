@@ -110,7 +110,7 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
         TST_REQUIRE(m->wout != nullptr, TST_ERR_ARG, "tst_tfm_step_run: null output projection");
         if (dma_vocab)
             TST_TRY(tst_gemm_dma_f32(m->ht, m->ld_ht, (const float*)m->wout, m->ld_wout, m->bout, (float*)m->logits, m->ld_logits, R, m->V, d,
-                                     2, stream));
+                                     3, stream));   // nontemporal stores: the logits leave the caches before they are read
         else
             TST_TRY(c.gemm(m->h, d, m->wout, m->ld_wout, m->bout, nullptr, 0, m->logits, m->ld_logits, m->V, d, 0, true));
     }
