@@ -667,6 +667,12 @@ bool tst_bf16_no_persist() {
     return v;
 }
 
+// TST_BF16_TILE=0|1|2 forces the 128 x 128, 256 x 128 or 256 x 256 tile (measurements)
+int tst_bf16_forced_shape() {
+    static const int v = [] { const char* e = getenv("TST_BF16_TILE"); return (e != nullptr && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1; }();
+    return v;
+}
+
 }  // namespace
 
 
@@ -686,9 +692,19 @@ extern "C" int tst_gemm_mfma_bf16(const void* A, int64_t lda, const void* W, int
     hipStream_t st = (hipStream_t)stream;
     const int variant = (out_bf16 ? 4 : 0) | (res != nullptr ? 2 : 0) | (act == 1 ? 1 : 0);
     if (K % DK == 0 && tst_aligned16(bias)) {
-        // LDS-DMA kernel: 256 x 256 tiles (8 waves) when they give every CU a workgroup, else 128 x 128 (4 waves)
-        const bool big = ((M + 255) / 256) * ((N + 255) / 256) >= 256;
-        const int64_t tm = big ? (M + 255) / 256 : (M + 127) / 128, tn = big ? (N + 255) / 256 : (N + 127) / 128;
+        // LDS-DMA kernel: 256 x 256 tiles (8 waves) when they give every CU a workgroup, else 256 x 128 (8 waves of 64 x 64) under
+        // the same condition, else 128 x 128 (4 waves).  The larger the tile, the fewer operand bytes pass through the CU's
+        // vector-memory path per MFMA (64 (TM + TN) / (TM TN) of its capacity: 0.5, 0.75, 1.0).
+        const int64_t big_tiles = ((M + 255) / 256) * ((N + 255) / 256), mid_tiles = ((M + 255) / 256) * ((N + 127) / 128);
+        // measured on the language model's shapes (K = 512 / 2048, 8 k - 64 k rows): a wide bf16 result (the vocabulary) is best
+        // on the persistent 256 x 256 kernel; q|k|v and ff1 (N <= 2048) on 256 x 128 at every row count (more tiles than CUs, two
+        // workgroups per CU: 4-10 % over 256 x 256); the fp32 + residual products on 256 x 256 from 192 tiles on
+        const bool plain_bf16 = out_bf16 && res == nullptr;
+        int shape = plain_bf16 ? (N >= 4096 && big_tiles >= 256 ? 2 : mid_tiles >= 128 ? 1 : 0)
+                               : (big_tiles >= 192 ? 2 : mid_tiles >= 128 ? 1 : 0);
+        if (const int forced = tst_bf16_forced_shape(); forced >= 0) shape = forced;
+        const bool big = shape == 2;
+        const int64_t tm = shape >= 1 ? (M + 255) / 256 : (M + 127) / 128, tn = shape == 2 ? (N + 255) / 256 : (N + 127) / 128;
         TST_REQUIRE(tm * tn < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_bf16: grid too large");
         const dim3 g2((unsigned)(tm * tn));
         if (big && out_bf16 && res == nullptr && K / DK >= 3 && !tst_bf16_no_persist()) {
@@ -704,8 +720,11 @@ extern "C" int tst_gemm_mfma_bf16(const void* A, int64_t lda, const void* W, int
         }
 #define TST_BF16_DMA(OB, HR, RL)                                                                                      \
     do {                                                                                                              \
-        if (big)                                                                                                      \
+        if (shape == 2)                                                                                               \
             hipLaunchKernelGGL((gemm_bf16_dma_kernel<2, 4, 4, 2, 3, OB, HR, RL>), g2, dim3(512), 0, st, (const __bf16*)A, lda, \
+                               (const __bf16*)W, ldw, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, (int)tm, (int)tn); \
+        else if (shape == 1)                                                                                          \
+            hipLaunchKernelGGL((gemm_bf16_dma_kernel<4, 2, 2, 2, 3, OB, HR, RL>), g2, dim3(512), 0, st, (const __bf16*)A, lda, \
                                (const __bf16*)W, ldw, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, (int)tm, (int)tn); \
         else                                                                                                          \
             hipLaunchKernelGGL((gemm_bf16_dma_kernel<2, 2, 2, 2, 4, OB, HR, RL>), g2, dim3(256), 0, st, (const __bf16*)A, lda, \
