@@ -35,7 +35,10 @@ def bf(x):
     return x.to(torch.bfloat16)
 
 
-@pytest.mark.parametrize('M,N,Kd', [(200, 300, 136), (1000, 1000, 512), (64, 32000, 64), (1, 8, 8), (129, 257, 2048)])
+# the last four reach the persistent 256 x 256 kernel (partial tiles in both directions, N % 8 != 0, K of exactly the ring depth),
+# the 256 x 128 tile and the 256 x 256 tile with a residual
+@pytest.mark.parametrize('M,N,Kd', [(200, 300, 136), (1000, 1000, 512), (64, 32000, 64), (1, 8, 8), (129, 257, 2048),
+                                    (4100, 4099, 96), (4100, 4100, 96), (4100, 4104, 512), (2100, 2000, 160), (4100, 3000, 64)])
 @pytest.mark.parametrize('mode', ['f32', 'f32_res', 'bf16_relu', 'bf16'])
 def test_gemm_bf16_against_float64(K, M, N, Kd, mode):
     g = torch.Generator(device='cuda').manual_seed(M * 7 + N)

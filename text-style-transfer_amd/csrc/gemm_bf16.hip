@@ -707,7 +707,8 @@ extern "C" int tst_gemm_mfma_bf16(const void* A, int64_t lda, const void* W, int
         const int64_t tm = shape >= 1 ? (M + 255) / 256 : (M + 127) / 128, tn = shape == 2 ? (N + 255) / 256 : (N + 127) / 128;
         TST_REQUIRE(tm * tn < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_bf16: grid too large");
         const dim3 g2((unsigned)(tm * tn));
-        if (big && out_bf16 && res == nullptr && K / DK >= 3 && !tst_bf16_no_persist()) {
+        // (N % 4: the persistent kernel fetches the bias in aligned groups of 4)
+        if (big && out_bf16 && res == nullptr && K / DK >= 3 && N % 4 == 0 && !tst_bf16_no_persist()) {
             // one workgroup per CU (the kernel's LDS allows no second one), a multiple of 8 so that every XCD has the same slots
             const dim3 gp(256);
             if (act == 1)
