@@ -12,7 +12,8 @@ import os
 import torch  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libtst_hip.so')
+# TST_HIP_LIB names another build of the same library (A/B measurements of kernel variants)
+LIB_PATH = os.environ.get('TST_HIP_LIB') or os.path.join(_HERE, 'libtst_hip.so')
 
 c_i64, c_i32, c_f32, c_vp, c_int = ctypes.c_int64, ctypes.c_int32, ctypes.c_float, ctypes.c_void_p, ctypes.c_int
 
