@@ -336,7 +336,7 @@ def main():
             'config': {'workload': workload, 'baseline_config': args.config, 'sentences_per_step': n_total,
                        'sentences_per_gpu_batch': args.batch, 'beam': args.beam, 'max_len': MAX_LEN, 'vocab': VOCAB,
                        'eos_bias': args.eos_bias, 'mean_emitted_len': emitted / (args.steps * n_total),
-                       'mean_emitted_len_note': 'eos_bias 5.5 gives ~23 tokens per sentence (the survey planned ~15); longer '
+                       'mean_emitted_len_note': 'eos_bias 5.5 gives ~23 tokens per sentence (~15 was the planning figure); longer '
                                                 'sentences mean more decode steps per batch, not fewer',
                        'decode_steps_per_batch': counters['loop_steps'] / n_batches,
                        'row_steps_per_batch': counters['rows'] / n_batches,

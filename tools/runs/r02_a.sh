@@ -1,5 +1,5 @@
 #!/bin/bash
-# round 2, first GPU call: no-alloc test, full GPU suite, peaks probe, bench lines (config 2, config 5 at N=1 and a 2-rank rehearsal)
+# one GPU call: no-alloc test, full GPU suite, peaks probe, bench lines (config 2, config 5 at N=1 and a 2-rank rehearsal)
 set -o pipefail
 mkdir -p gpurun_out/r02a
 O=gpurun_out/r02a
