@@ -89,20 +89,31 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
 
     // scores: 16 lanes per position, 4 positions per pass, 4 passes in flight (independent loads)
     for (int i0 = 0; i0 < nl; i0 += 16) {
+        // three phases, so that the pass costs one LDS wait and one memory wait instead of one of each per position:
+        // the rows of the 4 positions of this lane group, then all their loads, then the dot products
+        const T* kp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kp[u] = krow(min(i0 + 4 * u + g, nl - 1));
+        float4 kv[4][NCH];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int ch = j + 16 * c;
+                kv[u][c] = ld4(kp[u] + 4 * ((ch * 4 < dh) ? ch : 0));   // always a load (no branch); unused when beyond the head
+            }
         float part[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const T* kp = krow(min(i0 + 4 * u + g, nl - 1));
             float acc = 0.0f;
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int ch = j + 16 * c;
                 if (ch * 4 < dh) {
-                    const float4 kv = ld4(kp + 4 * ch);
-                    acc = __builtin_fmaf(qv[c].x, kv.x, acc);
-                    acc = __builtin_fmaf(qv[c].y, kv.y, acc);
-                    acc = __builtin_fmaf(qv[c].z, kv.z, acc);
-                    acc = __builtin_fmaf(qv[c].w, kv.w, acc);
+                    acc = __builtin_fmaf(qv[c].x, kv[u][c].x, acc);
+                    acc = __builtin_fmaf(qv[c].y, kv[u][c].y, acc);
+                    acc = __builtin_fmaf(qv[c].z, kv[u][c].z, acc);
+                    acc = __builtin_fmaf(qv[c].w, kv[u][c].w, acc);
                 }
             }
             part[u] = acc;
@@ -150,11 +161,18 @@ __global__ __launch_bounds__(256) void attn_step_kernel(
         for (int e = 0; e < VEC; ++e) acc[e] = 0.0f;
         for (int i0 = 0; i0 < nl; i0 += 8) {
             float wgt[8], v[8][VEC];
+            const T* vrow[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) vrow[u] = krow(min(i0 + u, nl - 1)) + d + c0;   // all LDS reads of the pass first
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = min(i0 + u, nl - 1);
-                wgt[u] = i0 + u < nl ? sc[w][SELF ? i : slot[w][i]] : 0.0f;   // beyond the list: weight 0, no effect
-                const T* vp = krow(i) + d + c0;
+                const float wv = sc[w][SELF ? i : slot[w][i]];   // read unconditionally (no branch per position)
+                wgt[u] = i0 + u < nl ? wv : 0.0f;                // beyond the list: weight 0, no effect
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const T* vp = vrow[u];
                 if (VEC == 4) {
                     const float4 x = ld4(vp);
                     v[u][0] = x.x; v[u][1 % VEC] = x.y; v[u][2 % VEC] = x.z; v[u][3 % VEC] = x.w;
@@ -387,9 +405,19 @@ __device__ __forceinline__ void attend_rows(const T* __restrict__ base, const in
 
     for (int i0 = 0; i0 < nl; i0 += 16) {
         float part[4][KB];
+        const T* kpp[4];    // rows first (LDS), then all loads, then the products
+#pragma unroll
+        for (int u = 0; u < 4; ++u) kpp[u] = krow(min(i0 + 4 * u + g, nl - 1));
+        float4 kvv[4][NCH];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                const int ch = j + 16 * c;
+                kvv[u][c] = ld4(kpp[u] + 4 * ((ch * 4 < dh) ? ch : 0));   // always a load; unused when beyond the head
+            }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const T* kp = krow(min(i0 + 4 * u + g, nl - 1));
             float acc[KB];
 #pragma unroll
             for (int b = 0; b < KB; ++b) acc[b] = 0.0f;
@@ -397,7 +425,7 @@ __device__ __forceinline__ void attend_rows(const T* __restrict__ base, const in
             for (int c = 0; c < NCH; ++c) {
                 const int ch = j + 16 * c;
                 if (ch * 4 < dh) {
-                    const float4 kv = ld4(kp + 4 * ch);
+                    const float4 kv = kvv[u][c];
 #pragma unroll
                     for (int b = 0; b < KB; ++b) {
                         acc[b] = __builtin_fmaf(qv[b][c].x, kv.x, acc[b]);
@@ -461,11 +489,17 @@ __device__ __forceinline__ void attend_rows(const T* __restrict__ base, const in
         for (int i0 = 0; i0 < nl; i0 += 8) {
             float v[8][VEC];
             int pos[8];
+            const T* vrow[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = min(i0 + u, nl - 1);
-                pos[u] = i0 + u < nl ? slot[i] : -1;
-                const T* vp = krow(i) + d + c0;
+                const int sl = slot[i];
+                pos[u] = i0 + u < nl ? sl : -1;
+                vrow[u] = krow(i) + d + c0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const T* vp = vrow[u];
                 if (VEC == 4) {
                     const float4 x = ld4(vp);
                     v[u][0] = x.x; v[u][1 % VEC] = x.y; v[u][2 % VEC] = x.z; v[u][3 % VEC] = x.w;
@@ -480,7 +514,8 @@ __device__ __forceinline__ void attend_rows(const T* __restrict__ base, const in
             for (int u = 0; u < 8; ++u)
 #pragma unroll
                 for (int b = 0; b < KB; ++b) {
-                    const float wgt = pos[u] >= 0 ? sc[b][pos[u]] : 0.0f;   // beyond the list: weight 0, no effect
+                    const float wv = sc[b][max(pos[u], 0)];                  // read unconditionally (no branch per position)
+                    const float wgt = pos[u] >= 0 ? wv : 0.0f;               // beyond the list: weight 0, no effect
 #pragma unroll
                     for (int e = 0; e < VEC; ++e) acc[b][e] = __builtin_fmaf(wgt, v[u][e], acc[b][e]);
                 }
