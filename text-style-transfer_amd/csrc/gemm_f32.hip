@@ -232,6 +232,156 @@ void launch_gemm(const float* A, int64_t lda, const float* Wt, int64_t ldw, cons
 #undef TST_GEMM_LAUNCH
 }
 
+// ---- 64 x 64 tiles with 32 k per tile ----------------------------------------------------------------------------------
+// The 64 x 64 x 16 tile above asks for 64 bytes of every A row per k-tile: half a cache line per request, and the second
+// half comes with the next tile, from the L2 again when four workgroups share the CU's 16 KB L1.  With 32 k per tile the
+// 8 lanes of a row ask for one whole line, and there are half as many barriers.  Same staging scheme (registers, k-major
+// LDS images, three buffers, the barrier in the middle of a tile), same fma chain per element; K % 32 == 0.
+// LDA = 66: the k-major A image is written by 8 lane groups (k) x 8 rows per wave, 4 * 66 * i mod 32 = 8 i spreads them
+// over the banks two deep (free for ds_write_b32).
+template <bool HAS_RES, bool RELU>
+__global__ __launch_bounds__(256) void gemm_f32_k32_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+                                                           int64_t ldw, const float* __restrict__ bias, const float* res, int64_t ldr,
+                                                           float* C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+    constexpr int BM = 64, BN = 64, KT = 32, LDA = 66, LDB = 68;
+    __shared__ __attribute__((aligned(16))) float As[3][KT][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[3][KT][LDB];
+
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
+    const int lb = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    const int per_group = GROUP_M * tiles_n;
+    const int first_m = (lb / per_group) * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (lb % per_group) % gsz;
+    const int tn = (lb % per_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // A: thread -> 16 bytes at k = 4 (t & 7) of rows (t >> 3) and (t >> 3) + 32; Wt: 16 bytes at n = 4 (t & 15) of k-rows (t >> 4), + 16
+    const int akq = (t & 7) * 4, ar = t >> 3;
+    const int bnq = (t & 15) * 4, bk = t >> 4;
+    const float* a_row0 = A + (int64_t)min(m0 + ar, M - 1) * lda + akq;
+    const float* a_row1 = A + (int64_t)min(m0 + ar + 32, M - 1) * lda + akq;
+    const float* w_p0 = W + (int64_t)bk * ldw + min(n0 + bnq, (int)ldw - 4);
+    const float* w_p1 = w_p0 + 16 * ldw;
+    float4 ra0, ra1, rb0, rb1;
+    auto load_tile = [&](int k0) {
+        ra0 = *reinterpret_cast<const float4*>(a_row0 + k0);
+        ra1 = *reinterpret_cast<const float4*>(a_row1 + k0);
+        rb0 = *reinterpret_cast<const float4*>(w_p0 + (int64_t)k0 * ldw);
+        rb1 = *reinterpret_cast<const float4*>(w_p1 + (int64_t)k0 * ldw);
+    };
+    auto store_tile = [&](int buf) {
+        As[buf][akq + 0][ar] = ra0.x; As[buf][akq + 1][ar] = ra0.y; As[buf][akq + 2][ar] = ra0.z; As[buf][akq + 3][ar] = ra0.w;
+        As[buf][akq + 0][ar + 32] = ra1.x; As[buf][akq + 1][ar + 32] = ra1.y; As[buf][akq + 2][ar + 32] = ra1.z; As[buf][akq + 3][ar + 32] = ra1.w;
+        *reinterpret_cast<float4*>(&Bs[buf][bk][bnq]) = rb0;
+        *reinterpret_cast<float4*>(&Bs[buf][bk + 16][bnq]) = rb1;
+    };
+
+    f32x16 acc;
+    {
+        const int col = n0 + wn * 32 + (lane & 31);
+        const float b = (bias != nullptr && col < N) ? bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = b;
+    }
+
+    const int nkt = K / KT;
+    load_tile(0);
+    store_tile(0);
+    if (nkt > 1) load_tile(KT);
+    __syncthreads();
+    const int arow = wm * 32 + (lane & 31), bcol = wn * 32 + (lane & 31), khalf = lane >> 5;
+    float a_cur = As[0][khalf][arow], b_cur = Bs[0][khalf][bcol], a_nxt = 0.f, b_nxt = 0.f;
+    int buf = 0;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const int nbuf = buf == 2 ? 0 : buf + 1;
+#pragma unroll
+        for (int kk = 0; kk < KT; kk += 2) {
+            if (kk + 2 < KT) {
+                a_nxt = As[buf][kk + 2 + khalf][arow];
+                b_nxt = Bs[buf][kk + 2 + khalf][bcol];
+            } else if (kt + 1 < nkt) {
+                a_nxt = As[nbuf][khalf][arow];
+                b_nxt = Bs[nbuf][khalf][bcol];
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur, b_cur, acc, 0, 0, 0);
+            a_cur = a_nxt;
+            b_cur = b_nxt;
+            if (kk == KT / 2 - 2) {
+                if (kt + 1 < nkt) {
+                    store_tile(nbuf);
+                    if (kt + 2 < nkt) load_tile((kt + 2) * KT);
+                }
+                __syncthreads();
+            }
+        }
+        buf = nbuf;
+    }
+
+    const bool full_tile = m0 + BM <= M && n0 + BN <= N;
+    const int col = n0 + wn * 32 + (lane & 31);
+    const int row0 = m0 + wm * 32 + 4 * (lane >> 5);
+    float rv[16];
+    if (full_tile) {
+        float* cp = C + (int64_t)row0 * ldc + col;
+        if (HAS_RES) {
+            const float* rp = res + (int64_t)row0 * ldr + col;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rv[r] = rp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldr];
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[r];
+            if (RELU) v = v > 0.0f ? v : 0.0f;
+            if (HAS_RES) v = v + rv[r];
+            cp[(int64_t)((r & 3) + 8 * (r >> 2)) * ldc] = v;
+        }
+    } else {
+        const bool col_ok = col < N;
+        if (HAS_RES) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + (r & 3) + 8 * (r >> 2);
+                rv[r] = (col_ok && row < M) ? res[(int64_t)row * ldr + col] : 0.0f;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2);
+            float v = acc[r];
+            if (RELU) v = v > 0.0f ? v : 0.0f;
+            if (HAS_RES) v = v + rv[r];
+            if (col_ok && row < M) C[(int64_t)row * ldc + col] = v;
+        }
+    }
+}
+
+void launch_gemm_k32(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res, int64_t ldr,
+                     float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, hipStream_t st) {
+    const int64_t tiles_m = (M + 63) / 64, tiles_n = (N + 63) / 64;
+    const dim3 grid((unsigned)(tiles_m * tiles_n));
+#define TST_K32_LAUNCH(HR, RL)                                                                                         \
+    hipLaunchKernelGGL((gemm_f32_k32_kernel<HR, RL>), grid, dim3(256), 0, st, A, lda, Wt, ldw, bias, res, ldr, C, ldc, (int)M, (int)N, \
+                       (int)K, (int)tiles_m, (int)tiles_n)
+    if (res != nullptr) {
+        if (act == 1) TST_K32_LAUNCH(true, true); else TST_K32_LAUNCH(true, false);
+    } else {
+        if (act == 1) TST_K32_LAUNCH(false, true); else TST_K32_LAUNCH(false, false);
+    }
+#undef TST_K32_LAUNCH
+}
+
+bool tst_gemm_no_k32() {
+    static const bool v = [] { const char* e = getenv("TST_GEMM_NO_K32"); return e != nullptr && e[0] == '1'; }();
+    return v;
+}
+
 // ---- small problems -------------------------------------------------------------------------------------------------
 // With few output elements the 64 x 64 tiling leaves most of the 1024 SIMDs idle and every tile is one dependent chain of
 // K / 2 MFMAs of 64 cycles.  Here one WAVE owns a 16 x (16 * NT) strip of C and uses v_mfma_f32_16x16x4_f32 (same
@@ -595,6 +745,8 @@ extern "C" int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, i
         launch_gemm<2, 4>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
     else if (big_tiles >= 640)
         launch_gemm<2, 2>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
+    else if (K % 32 == 0 && !tst_gemm_no_k32())
+        launch_gemm_k32(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
     else
         launch_gemm<1, 1>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
     return tst_after_launch("tst_gemm_mfma_f32");
