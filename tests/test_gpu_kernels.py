@@ -50,8 +50,11 @@ def _gemm_case(K, M, N, K_, bias, act, res, strip=None, odd_ldc=False):
 
 
 @pytest.mark.parametrize('M,N,K_,bias,act,res', GEMM_SHAPES + [
-    (2100, 520, 132, True, 1, True),      # beyond the small-problem kernel: 64 x 64 tiles
-    (4100, 2000, 64, True, 0, True)])     # 128 x 128 tiles
+    (2100, 520, 132, True, 1, True),      # beyond the small-problem kernel: 64 x 64 x 16 tiles (K % 32 != 0)
+    (2100, 520, 128, True, 1, True),      # 64 x 64 x 32 tiles: relu + residual, partial tiles in both directions
+    (3000, 300, 256, False, 0, False),    # 64 x 64 x 32 tiles, no bias
+    (4100, 2000, 64, True, 0, True),      # 64 x 64 x 32 tiles, two k-tiles only
+    (11000, 1100, 48, True, 0, True)])    # 128 x 128 tiles
 def test_gemm_bit_exact(K, M, N, K_, bias, act, res):
     _gemm_case(K, M, N, K_, bias, act, res)
 
