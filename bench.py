@@ -196,8 +196,8 @@ def checksum(tok, lens):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=None, help='timed steps (default 3; 1 for --config 5)')
-    ap.add_argument('--warmup', type=int, default=None, help='untimed steps before (default 1)')
+    ap.add_argument('--steps', type=int, default=None, help='timed steps (default 5; 1 for --config 5)')
+    ap.add_argument('--warmup', type=int, default=None, help='untimed steps before (default 2; 1 for --config 5)')
     ap.add_argument('--config', type=int, default=2, choices=(2, 5), help='BASELINE.json config: 2 = one 8k-sentence batch per GPU '
                     'per step (weak scaling, the headline); 5 = a fixed corpus sharded over the GPUs (strong scaling)')
     ap.add_argument('--sentences', type=int, default=1000000, help='--config 5: sentences in the corpus')
@@ -213,9 +213,9 @@ def main():
     ap.add_argument('--share-gpu', action='store_true', help='rehearsal: all ranks use GPU 0 (a one-GPU box)')
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 1 if args.config == 5 else 3
+        args.steps = 1 if args.config == 5 else 5
     if args.warmup is None:
-        args.warmup = 1
+        args.warmup = 1 if args.config == 5 else 2   # the first batches on a fresh box run 2-5 % slow (clocks, first touches)
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
