@@ -105,7 +105,10 @@ int tst_add_rows_f32(float* x, const float* z, const int32_t* idx, int64_t R, in
  * A [M][lda] and W [N][ldw] are bf16 with k contiguous (W is the nn.Linear weight as stored, [out][in]).
  * epilogue = relu if act == 1, then + res[m][n] (fp32, may alias an fp32 C) if res != NULL; C is bf16 if
  * out_bf16 != 0, else fp32.  Requirements: K, lda, ldw multiples of 8; ldc a multiple of 8 (bf16) or 4
- * (fp32); ldr a multiple of 4; 16-byte aligned A, W, C, res. */
+ * (fp32); ldr a multiple of 4; 16-byte aligned A, W, C, res.
+ * bf16 results are written with nontemporal stores (a wide result such as the logits is read again only after it has
+ * left the caches); large bf16 products without a residual run as one persistent workgroup per CU.  Tile shape and
+ * kernel form are chosen from M, N, K and never change the value of an element. */
 int tst_gemm_mfma_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* res,
                        int64_t ldr, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, int out_bf16,
                        void* stream);
