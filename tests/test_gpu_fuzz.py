@@ -1,0 +1,114 @@
+"""Seeded random configurations of the transformer decode path (model sizes, head counts, vocabulary, batch, source lengths,
+beam, length penalty, max_len) against the canonical oracle, bit for bit: tokens, hypothesis scores and output lengths.
+The cases are drawn to reach what the fixed-size tests do not: one-sentence and one-position batches, heads of 8 to 128
+elements, beams wider than the vocabulary's live mass, max_len of 1, sentences that never end, batches that all end at once,
+row counts on both sides of the loop's small-batch switches."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import canon as C
+from oracle import torch_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def T():
+    import tst_amd
+    assert torch.cuda.is_available()
+    return tst_amd
+
+
+def draw(seed):
+    r = np.random.RandomState(1000 + seed)
+    heads = int(r.choice([1, 2, 4, 8]))
+    dh = int(r.choice([8, 16, 32, 64, 128]))
+    while heads * dh > 512:
+        dh //= 2
+    d = heads * dh
+    return dict(hp=R.mt_hp(d_model=d, n_heads=heads, n_layers=int(r.choice([1, 2, 3])), d_ff=int(r.choice([16, 64, 256, 1024]))),
+                V=int(r.choice([5, 17, 64, 300, 1000, 5000])), B=int(r.choice([1, 2, 7, 33, 100, 300])), S=int(r.choice([1, 2, 9, 23])),
+                max_len=int(r.choice([1, 2, 7, 19, 40])), beam=int(r.choice([1, 1, 2, 3, 4, 8])), alpha=float(r.choice([0.0, 0.0, 0.6, 1.0])),
+                eos_bias=float(r.choice([-2.0, 0.5, 2.0, 4.0, 9.0])))
+
+
+@pytest.mark.parametrize('seed', range(28))
+def test_random_configuration_bit_exact(T, seed):
+    c = draw(seed)
+    hp, V, B, S, max_len, beam, alpha = c['hp'], c['V'], c['B'], c['S'], c['max_len'], c['beam'], c['alpha']
+    tv = R.synthetic_vocab(V)
+    tmodel = R.synthetic_init(R.Transformer(R.HP(hp), tv, tv), 3, c['eos_bias'], 2.0, seed=seed)
+    vocab = T.Vocab.synthetic(V)
+    model = T.Transformer(T.HP(hp), vocab, vocab)
+    model.load_state_dict(tmodel.state_dict())
+    r = np.random.RandomState(seed)
+    lens = r.randint(1, S + 1, size=B)
+    encs = r.standard_normal((B, S, hp['d_model'])).astype(np.float32)
+    mask = (np.arange(S)[None] < lens[:, None])[:, None, :]
+    st = T.InferenceState({'model': model.decoder, 'inputs': torch.from_numpy(encs).cuda(), 'enc_mask': torch.from_numpy(mask).cuda(),
+                           'vocab': vocab, 'max_len': max_len, 'beam_size': beam, 'length_penalty': alpha})
+    out = [[int(t) for t in s.tolist()] for s in st.inference()]
+    sess = C.CanonTransformerDecoder(tmodel.decoder, hp['n_heads']).session(encs, mask, beam, max_len)
+    if beam == 1:
+        want, _, _ = C.greedy_decode(sess, B, max_len, 2, 3, 0)
+    else:
+        want, scores, _, _ = C.beam_decode(sess, B, beam, max_len, 2, 3, alpha, 0)
+        assert np.array_equal(st.scores.cpu().numpy(), scores), c
+    assert out == want, c
+    assert all(1 <= len(s) <= 1 + max_len and s[0] == 2 for s in out)
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_random_whole_path_from_source_ids(T, seed):
+    """Source ids with ragged padding -> encoder pass -> decode, as transformer_mt_trainer.py:91-98 calls it: encoder output at
+    every real position, tokens and scores, bit for bit."""
+    c = draw(100 + seed)
+    hp, V, B, S, max_len, beam, alpha = c['hp'], max(c['V'], 17), c['B'], max(c['S'], 2), max(c['max_len'], 2), c['beam'], c['alpha']
+    tv = R.synthetic_vocab(V)
+    tmodel = R.synthetic_init(R.Transformer(R.HP(hp), tv, tv), 3, c['eos_bias'], 2.0, seed=seed)
+    vocab = T.Vocab.synthetic(V)
+    model = T.Transformer(T.HP(hp), vocab, vocab)
+    model.load_state_dict(tmodel.state_dict())
+    r = np.random.RandomState(seed)
+    lens = r.randint(1, S + 1, size=B)
+    lens[r.randint(B)] = S                                     # one sentence fills the padded width
+    src = np.where(np.arange(S)[None] < lens[:, None], r.randint(4, V, size=(B, S)), 1).astype(np.int64)
+    encs, enc_mask = model.encoder(torch.from_numpy(src).cuda())
+    want_encs, want_mask = C.CanonTransformerEncoder(tmodel.encoder, hp['n_heads'])(src)
+    real = want_mask[:, 0, :]
+    assert np.array_equal(encs.cpu().numpy()[real], want_encs[real])
+    st = T.InferenceState({'model': model.decoder, 'inputs': encs, 'enc_mask': enc_mask, 'vocab': vocab, 'max_len': max_len,
+                           'beam_size': beam, 'length_penalty': alpha})
+    out = [[int(t) for t in s.tolist()] for s in st.inference()]
+    sess = C.CanonTransformerDecoder(tmodel.decoder, hp['n_heads']).session(want_encs, want_mask, beam, max_len)
+    if beam == 1:
+        want, _, _ = C.greedy_decode(sess, B, max_len, 2, 3, 0)
+    else:
+        want, scores, _, _ = C.beam_decode(sess, B, beam, max_len, 2, 3, alpha, 0)
+        assert np.array_equal(st.scores.cpu().numpy(), scores), c
+    assert out == want, c
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_random_gru_decoder(T, seed):
+    """GRU decoder (RNNDecoder(emb, hid, vocab), cyclegan_trainer.py:64) at random sizes, greedy and beam."""
+    r = np.random.RandomState(2000 + seed)
+    E, H = int(r.choice([16, 64, 96, 256])), int(r.choice([32, 64, 192, 512]))
+    V, B = int(r.choice([9, 40, 128, 700])), int(r.choice([1, 3, 40, 200, 2100]))
+    max_len, beam = int(r.choice([1, 5, 30])), int(r.choice([1, 1, 2, 4]))
+    tv = R.synthetic_vocab(V)
+    tmodel = R.synthetic_init(R.RNNDecoder(E, H, tv), 3, float(r.choice([0.0, 1.5, 3.0])), 2.0, seed=seed)
+    vocab = T.Vocab.synthetic(V)
+    model = T.RNNDecoder(E, H, vocab)
+    model.load_state_dict(tmodel.state_dict())
+    z = r.standard_normal((B, H)).astype(np.float32)
+    st = T.InferenceState({'model': model, 'inputs': torch.from_numpy(z).cuda(), 'vocab': vocab, 'max_len': max_len, 'beam_size': beam})
+    out = [[int(t) for t in s.tolist()] for s in st.inference()]
+    sess = C.CanonGRUDecoder(tmodel).session(z, beam)
+    if beam == 1:
+        want, _, _ = C.greedy_decode(sess, B, max_len, 2, 3, 0)
+    else:
+        want, scores, _, _ = C.beam_decode(sess, B, beam, max_len, 2, 3, 0.0, 0)
+        assert np.array_equal(st.scores.cpu().numpy(), scores)
+    assert out == want, (E, H, V, B, max_len, beam)
