@@ -112,3 +112,30 @@ def test_random_gru_decoder(T, seed):
         want, scores, _, _ = C.beam_decode(sess, B, beam, max_len, 2, 3, 0.0, 0)
         assert np.array_equal(st.scores.cpu().numpy(), scores)
     assert out == want, (E, H, V, B, max_len, beam)
+
+
+@pytest.mark.parametrize('seed', range(24))
+def test_random_gemm_shapes_bit_exact(seed):
+    """tst_gemm_mfma_f32 at random shapes across every kernel the dispatcher can pick (strip kernels, 64 x 64 x 16, 64 x 64 x 32,
+    128 x 128, 128 x 256 tiles), with and without bias / relu / residual: equal to the k-ordered fma chain of the oracle."""
+    from tst_amd import kernels as K
+    r = np.random.RandomState(3000 + seed)
+    M = int(r.choice([1, 3, 17, 100, 257, 1000, 2100, 4100, 9000]))
+    N = int(r.choice([1, 8, 33, 90, 256, 520, 1000, 2304]))
+    Kd = int(r.choice([4, 20, 36, 64, 132, 256, 512, 1024]))
+    while M * N * Kd > 5e8:
+        M = max(1, M // 2)
+    bias, act, res = bool(r.randint(2)), int(r.randint(2)), bool(r.randint(2))
+    A = r.standard_normal((M, Kd)).astype(np.float32)
+    W = r.standard_normal((Kd, N)).astype(np.float32)
+    b = r.standard_normal(N).astype(np.float32) if bias else None
+    R0 = r.standard_normal((M, N)).astype(np.float32) if res else None
+    ldw = (N + 3) // 4 * 4
+    Wd = torch.zeros((Kd, ldw), dtype=torch.float32, device='cuda')
+    Wd[:, :N] = torch.from_numpy(W).cuda()
+    out = torch.full((M, ldw), 7.0, dtype=torch.float32, device='cuda')
+    K.gemm(torch.from_numpy(A).cuda(), Wd[:, :N], None if b is None else torch.from_numpy(b).cuda(), out, M, n_cols=N,
+           res=None if R0 is None else torch.from_numpy(R0).cuda(), act=act)
+    got = out.cpu().numpy()
+    assert np.array_equal(got[:, :N], C.gemm(A, W, b, R0, act)), (M, N, Kd, bias, act, res)
+    assert (got[:, N:] == 7.0).all()
