@@ -72,6 +72,19 @@ __device__ __forceinline__ void load_chunk(const __bf16* xr, int c, int V, bool 
     for (int q = 0; q < 8; ++q) o[q] = 8 * c + q < V ? (float)xr[8 * c + q] : -INFINITY;
 }
 
+// a chunk that lies fully inside the row, first pass.  bf16 rows are read nontemporally (+10 % on that pass: 4.4 -> 4.85 TB/s)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void load_chunk_nt(const float* xr, int c, float (&o)[4]) {
+    load_chunk(xr, c, INT_MAX, true, o);   // fp32 rows: measured equal or slower nontemporal inside the decode loop: ordinary loads
+}
+__device__ __forceinline__ void load_chunk_nt(const __bf16* xr, int c, float (&o)[8]) {
+    const u32x4_t u = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(xr) + c);
+    o[0] = __uint_as_float(u[0] << 16); o[1] = __uint_as_float(u[0] & 0xffff0000u);
+    o[2] = __uint_as_float(u[1] << 16); o[3] = __uint_as_float(u[1] & 0xffff0000u);
+    o[4] = __uint_as_float(u[2] << 16); o[5] = __uint_as_float(u[2] & 0xffff0000u);
+    o[6] = __uint_as_float(u[3] << 16); o[7] = __uint_as_float(u[3] & 0xffff0000u);
+}
+
 // One workgroup of BLOCK threads per row.  With few rows (one workgroup per CU or less) 1024 threads put four times as
 // many loads in flight per row; the first maximal index is the same whatever the split.
 template <typename T, int BLOCK>
@@ -197,7 +210,7 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const T* __restric
         for (; c0 + 768 < nfull; c0 += 1024) {
             float vv[4][EPC];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) load_chunk(xr, c0 + 256 * u, INT_MAX, true, vv[u]);
+            for (int u = 0; u < 4; ++u) load_chunk_nt(xr, c0 + 256 * u, vv[u]);
             lse_consume<EPC>(vv, m, sacc);
         }
     }
