@@ -284,7 +284,9 @@ int tst_retire_compact(const tst_rows* cur, const tst_rows* nxt, const int32_t* 
  * and results as tst_retire_compact without scratch_alive_pos: the 2 * n_sent int32 of alive flags and prefix sums live in an
  * array inside the library's code object (512 KiB, held on every GPU the library runs on until the process ends).
  * n_sent <= TST_NOALLOC_MAX_SENT, else TST_ERR_UNSUPPORTED.  Calls no hipMalloc / hipFree; the first call on a device
- * resolves that device's copy of the array (hipGetSymbolAddress, the device must be current as for any launch).  All calls
+ * resolves that device's copy of the array (hipGetSymbolAddress, the device must be current as for any launch): that
+ * lookup may load the code object or synchronise, so make ONE warm-up call per device outside any stream capture (any
+ * valid arguments, n_sent = 0 included); every later call on that device only launches kernels.  All calls
  * on one GPU share the array: calls that overlap there (different streams or threads) race; calls on one stream do not. */
 #define TST_NOALLOC_MAX_SENT 65536
 int tst_retire_compact_noalloc(const tst_rows* cur, const tst_rows* nxt, const int32_t* sel_parent, const int32_t* sel_tok,

@@ -248,6 +248,40 @@ def test_encoder_computes_only_real_positions_wherever_the_padding_is(T):
     assert np.array_equal(encs.cpu().numpy()[0, 0], want[0, 0])
 
 
+def test_encoder_outputs_edited_in_place_are_repacked(T):
+    """The decoder takes the encoder's packed rows as they are only while ``encs`` / ``enc_mask`` are unedited; after an
+    in-place edit (a style vector added to ``encs``, a source position masked out) it must decode from the edited tensors,
+    as the reference does (``encs`` is passed by value, /root/reference/src/trainers/transformer_mt_trainer.py:91-94)."""
+    fx = load_fixture('tfm_v1000')
+    cfg = fx['config']
+    _, model, vocab = native_models(T, cfg)
+    src = torch.from_numpy(fx['src']).long().cuda()
+
+    def decode(encs, enc_mask):
+        st = T.InferenceState({'model': model.decoder, 'inputs': encs, 'enc_mask': enc_mask, 'vocab': vocab, 'max_len': cfg['max_len']})
+        out = seqs_of(st.inference(keep_logits=1))
+        return out, st.loop.kept[0][0].cpu().numpy().copy()
+
+    encs, enc_mask = model.encoder(src)
+    base_seqs, base_logits = decode(encs, enc_mask)
+    assert base_seqs == fx['seqs']
+    style = torch.randn(cfg['hp']['d_model'], generator=torch.Generator().manual_seed(3)).cuda()
+    # edit in place: same tensor objects, the attribute set by the encoder is still there
+    encs, enc_mask = model.encoder(src)
+    encs.add_(style)
+    enc_mask[:, :, 1] = False
+    assert getattr(encs, '_tst_packed', None) is not None
+    got_seqs, got_logits = decode(encs, enc_mask)
+    # the same edit on copies (fresh objects: packed here from the tensors)
+    want_seqs, want_logits = decode(encs.clone(), enc_mask.clone())
+    assert got_seqs == want_seqs and np.array_equal(got_logits, want_logits)
+    assert not np.array_equal(got_logits, base_logits)             # the edit changes the logits: stale rows would be caught
+    # unedited outputs still take the packed rows (same results as packing here)
+    encs, enc_mask = model.encoder(src)
+    again_seqs, again_logits = decode(encs.clone(), enc_mask.clone())
+    assert again_seqs == base_seqs and np.array_equal(again_logits, base_logits)
+
+
 def test_stack_finished_and_errors(T):
     fx = load_fixture('gru_h32')
     _, model, vocab = native_models(T, fx['config'])

@@ -96,7 +96,10 @@ class TransformerEncoder(HipModule):
         K.scatter_rows(h, packed.padded_row, encs, n)
         encs = encs.view(B, S, d)
         # the decoder session of this package can take the packed rows as they are (no second packing pass) when it is handed
-        # these two tensor objects unchanged
+        # these two tensor objects unchanged: same objects AND same contents (the version counters recorded here move with
+        # every in-place edit, e.g. ``encs.add_(style)`` or ``enc_mask[..., j] = False``, after which the session repacks
+        # from the tensors it is given)
         packed.rows = h
+        packed.versions = (encs._version, enc_mask._version)
         encs._tst_packed = enc_mask._tst_packed = packed
         return encs, enc_mask

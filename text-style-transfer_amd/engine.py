@@ -55,10 +55,13 @@ _PINNED = {}
 
 
 def _pinned_counts(dev):
-    """Two int32 of page-locked host memory per device for the late reads of the survivor counts (allocating page-locked
-    memory per decode call would cost more than the reads save).  One decode loop runs at a time per host thread and device."""
-    key = (str(dev), __import__('threading').get_ident())
+    """Two int32 of page-locked host memory per (device, host thread, stream) for the late reads of the survivor counts
+    (allocating page-locked memory per decode call would cost more than the reads save).  A lagged loop waits for its last
+    copy into the buffer before it returns, so a later loop that gets the same buffer never sees a copy still in flight."""
+    key = (str(dev), __import__('threading').get_ident(), torch.cuda.current_stream(dev).cuda_stream)
     if key not in _PINNED:
+        if len(_PINNED) > 256:
+            _PINNED.clear()
         _PINNED[key] = torch.zeros(2, dtype=torch.int32).pin_memory()
     return _PINNED[key]
 
@@ -219,6 +222,7 @@ class DecodeLoop:
         host = _pinned_counts(self.dev)
         events = (torch.cuda.Event(), torch.cuda.Event())
         bound = self.B                                              # upper bound of the sentences entering the coming step
+        last = None
         for t in range(T):
             k_in = 1 if t == 0 else k
             R = bound * k_in
@@ -240,6 +244,7 @@ class DecodeLoop:
             self.tail.run(self.cur, self.nxt, bound, k_in, pos0 + t, t, t == T - 1)
             host[t % 2:t % 2 + 1].copy_(counts[t % 2], non_blocking=True)
             events[t % 2].record()
+            last = events[t % 2]
             self.cur, self.nxt = self.nxt, self.cur
             self.steps_done += 1
             self.rows_stepped += R
@@ -260,4 +265,6 @@ class DecodeLoop:
                 break
             s.reorder(self.row_parent, entering * k, identity=False)
             bound = entering
+        if last is not None:
+            last.synchronize()      # the last copy into the pinned buffer has landed: the buffer may be handed to another loop
         return self.out_tok, self.out_len, self.out_score

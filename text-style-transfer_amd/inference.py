@@ -162,66 +162,66 @@ class InferenceState:
                     raise ValueError('the model computes in %s, dtype=%r was asked for' % (have, self.dtype))
                 self.model.set_dtype(self.dtype)
                 restore_dtype = have      # the switch lasts for this call only: the caller's model is handed back as it came
-        if self.sample_type not in ('max', 'sample'):
-            raise NotImplementedError  # as /root/reference/src/inference.py:149
-        sample = None
-        if self.sample_type == 'sample':
-            if self.beam_size != 1:
-                raise ValueError("sample_type='sample' needs beam_size 1")
-            seed = self.seed if self.seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-            sample = (float(self.temperature), seed)
-        prefix = None
-        if self.active_seqs is not None and not self.gumbel:
-            prefix = self.active_seqs
-            if prefix.dim() != 2 or prefix.shape[0] != self.batch_size or prefix.shape[1] < 1 or prefix.is_floating_point():
-                raise ValueError('active_seqs must be token ids [batch, t0 >= 1]')
-            if int(prefix.min()) < 0 or int(prefix.max()) >= len(self.vocab):   # nn.Embedding raises IndexError there
-                raise IndexError('active_seqs holds token ids outside the vocabulary (0..%d)' % (len(self.vocab) - 1))
-        if not torch.cuda.is_available():
-            raise RuntimeError('InferenceState needs a GPU: the decode loop runs in HIP kernels and has no CPU path')
-        device = self.inputs.device if self.inputs.is_cuda else torch.device('cuda', torch.cuda.current_device())
-        gumbel = None
-        if self.gumbel:
-            if self.beam_size != 1:
-                raise ValueError('gumbel=True needs beam_size 1')
-            if self.substitute_inputs:
-                # /root/reference/src/inference.py:128 slices [B, 1, t * V] along its middle axis: empty from step 1 on
-                raise NotImplementedError('gumbel decoding of a stateful model')
-            if self.noise not in ('torch', 'device'):
-                raise ValueError("noise must be 'torch' or 'device'")
-            V = len(self.vocab)
-            if self.active_seqs is None:
-                dist_prefix = torch.zeros((self.batch_size, V), dtype=torch.float32, device=device)
-                dist_prefix[:, self.bos_idx] = 1.0
-            else:
-                if tuple(self.active_seqs.shape) != (self.batch_size, 1, V) or not self.active_seqs.is_floating_point():
-                    raise NotImplementedError('gumbel=True takes active_seqs as one distribution per sentence: [B, 1, V] floats')
-                dist_prefix = self.active_seqs[:, 0].to(device=device, dtype=torch.float32)
-            if self.noise == 'torch':
-                draw = lambda n, v: torch.rand((n, v)).to(device)            # noqa: E731
-            else:
-                draw = lambda n, v: torch.rand((n, v), device=device)        # noqa: E731
-            gumbel = (float(self.temperature), dist_prefix, draw)
-        with torch.cuda.device(device):
-            total = self.max_len if prefix is None else self.max_len + prefix.shape[1] - 1
-            session = self._session(total)
-            if prefix is not None and prefix.shape[1] > 1:
-                if isinstance(session, ForeignSession):
-                    session.pos0 = prefix.shape[1] - 1
-                elif self.substitute_inputs:
-                    # /root/reference/src/inference.py:128 feeds active_seqs[:, num_steps_done:], so with a prefix of t0 > 1
-                    # tokens a stateful model is given t0 tokens at EVERY step (the last t0 - 1 of them again); a session
-                    # that carries its state consumes each token once and would give different results
-                    raise NotImplementedError('an id prefix longer than one token together with substitute_inputs is only '
-                                              'supported for foreign model callables')
-            loop = DecodeLoop(session, self.batch_size, self.beam_size, self.max_len, self.bos_idx,
-                              self.eos_idx, self.pad_idx, self.length_penalty, device, sample, gumbel, prefix)
-            loop.select_log = getattr(self, 'select_log', None)
-            try:
+        try:   # everything after the switch: validation, session and loop set-up can raise too
+            if self.sample_type not in ('max', 'sample'):
+                raise NotImplementedError  # as /root/reference/src/inference.py:149
+            sample = None
+            if self.sample_type == 'sample':
+                if self.beam_size != 1:
+                    raise ValueError("sample_type='sample' needs beam_size 1")
+                seed = self.seed if self.seed is not None else int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+                sample = (float(self.temperature), seed)
+            prefix = None
+            if self.active_seqs is not None and not self.gumbel:
+                prefix = self.active_seqs
+                if prefix.dim() != 2 or prefix.shape[0] != self.batch_size or prefix.shape[1] < 1 or prefix.is_floating_point():
+                    raise ValueError('active_seqs must be token ids [batch, t0 >= 1]')
+                if int(prefix.min()) < 0 or int(prefix.max()) >= len(self.vocab):   # nn.Embedding raises IndexError there
+                    raise IndexError('active_seqs holds token ids outside the vocabulary (0..%d)' % (len(self.vocab) - 1))
+            if not torch.cuda.is_available():
+                raise RuntimeError('InferenceState needs a GPU: the decode loop runs in HIP kernels and has no CPU path')
+            device = self.inputs.device if self.inputs.is_cuda else torch.device('cuda', torch.cuda.current_device())
+            gumbel = None
+            if self.gumbel:
+                if self.beam_size != 1:
+                    raise ValueError('gumbel=True needs beam_size 1')
+                if self.substitute_inputs:
+                    # /root/reference/src/inference.py:128 slices [B, 1, t * V] along its middle axis: empty from step 1 on
+                    raise NotImplementedError('gumbel decoding of a stateful model')
+                if self.noise not in ('torch', 'device'):
+                    raise ValueError("noise must be 'torch' or 'device'")
+                V = len(self.vocab)
+                if self.active_seqs is None:
+                    dist_prefix = torch.zeros((self.batch_size, V), dtype=torch.float32, device=device)
+                    dist_prefix[:, self.bos_idx] = 1.0
+                else:
+                    if tuple(self.active_seqs.shape) != (self.batch_size, 1, V) or not self.active_seqs.is_floating_point():
+                        raise NotImplementedError('gumbel=True takes active_seqs as one distribution per sentence: [B, 1, V] floats')
+                    dist_prefix = self.active_seqs[:, 0].to(device=device, dtype=torch.float32)
+                if self.noise == 'torch':
+                    draw = lambda n, v: torch.rand((n, v)).to(device)            # noqa: E731
+                else:
+                    draw = lambda n, v: torch.rand((n, v), device=device)        # noqa: E731
+                gumbel = (float(self.temperature), dist_prefix, draw)
+            with torch.cuda.device(device):
+                total = self.max_len if prefix is None else self.max_len + prefix.shape[1] - 1
+                session = self._session(total)
+                if prefix is not None and prefix.shape[1] > 1:
+                    if isinstance(session, ForeignSession):
+                        session.pos0 = prefix.shape[1] - 1
+                    elif self.substitute_inputs:
+                        # /root/reference/src/inference.py:128 feeds active_seqs[:, num_steps_done:], so with a prefix of t0 > 1
+                        # tokens a stateful model is given t0 tokens at EVERY step (the last t0 - 1 of them again); a session
+                        # that carries its state consumes each token once and would give different results
+                        raise NotImplementedError('an id prefix longer than one token together with substitute_inputs is only '
+                                                  'supported for foreign model callables')
+                loop = DecodeLoop(session, self.batch_size, self.beam_size, self.max_len, self.bos_idx,
+                                  self.eos_idx, self.pad_idx, self.length_penalty, device, sample, gumbel, prefix)
+                loop.select_log = getattr(self, 'select_log', None)
                 loop.run(keep_logits)
-            finally:
-                if restore_dtype is not None:
-                    self.model.set_dtype(restore_dtype)
+        finally:
+            if restore_dtype is not None:
+                self.model.set_dtype(restore_dtype)
         self.loop = loop
         self.step_logits = [(lg, sent) for lg, sent, _ in loop.kept]
         self.num_steps_done = max(0, loop.steps_done - 1)   # index of the last step, as /root/reference/src/inference.py:156 leaves it

@@ -229,8 +229,9 @@ class TransformerSession:
         if max_len > W['pe'].shape[0]:
             raise ValueError('max_len %d exceeds pe_max_len %d' % (max_len, W['pe'].shape[0]))
         packed = getattr(encs, '_tst_packed', None)
-        if packed is None or packed is not getattr(enc_mask, '_tst_packed', None) or packed.rows.device != dev:
-            packed = None     # not the untouched outputs of this package's encoder: pack here
+        if (packed is None or packed is not getattr(enc_mask, '_tst_packed', None) or packed.rows.device != dev
+                or getattr(packed, 'versions', None) != (encs._version, enc_mask._version)):
+            packed = None     # not the untouched outputs of this package's encoder (other objects, or edited in place): pack here
         encs = encs.to(device=dev, dtype=torch.float32).contiguous()
         B, S, d = encs.shape
         if d != dec.d:
