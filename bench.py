@@ -226,7 +226,13 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    if world > 1:
+        # N ranks share this host: each takes its share of the cores the job may use (set-up would otherwise run N x all threads)
+        share = max(1, cpu_threads() // world)
+        os.environ['OMP_NUM_THREADS'] = str(share)
     import torch
+    if world > 1:
+        torch.set_num_threads(share)
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -244,15 +250,18 @@ def main():
     from tst_amd import synthetic
     model, vocab = build_model(device, args.eos_bias)
 
-    # the sentences of the job, the same on every rank; each rank keeps its shard resident in HBM before the timed region
+    # the sentences of the job: every rank derives the same plan from the sentence LENGTHS of the corpus (cheap) and then
+    # builds only its own shard of it (same seed, same random stream: the rows other ranks own are dropped chunk by chunk);
+    # the shard is resident in HBM before the timed region
     n_total = args.sentences if args.config == 5 else world * args.batch
-    src_all = synthetic.multi30k_like_sources(n_total, VOCAB, seed=1236 if args.config == 2 else 1240)
-    src_lens = (src_all != 1).sum(1)
+    corpus_seed = 1236 if args.config == 2 else 1240
+    src_lens = torch.from_numpy(synthetic.multi30k_like_lengths(n_total, corpus_seed) + 2)     # + BOS and EOS
     order, per_rank = shard.shard_plan(src_lens, world)
     mine = shard.my_shard(order, world, rank)
-    src = src_all[mine].to(device)
+    mine_sorted, back = torch.sort(mine)
+    src = synthetic.multi30k_like_sources(n_total, VOCAB, seed=corpus_seed, rows=mine_sorted.numpy())
+    src = src[torch.argsort(back)].to(device)      # walking order: the rank's sentences by length
     my_lens = src_lens[mine]            # host: the walk trims every batch to its longest sentence
-    del src_all
 
     def barrier():
         torch.cuda.synchronize()
@@ -260,7 +269,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    counters = {'rows': 0, 'loop_steps': 0, 'batches': 0}
+    counters = {'rows': 0, 'loop_steps': 0, 'batches': 0, 'gather_s': 0.0}
 
     def decode_fn(batch):
         tok, lens, loop = decode_batch(model, vocab, batch, args.beam, args.alpha)
@@ -277,9 +286,16 @@ def main():
         else:
             tok, lens = decode_fn(src)
         if world > 1:
+            # the decode is complete on this rank before its outputs can be gathered; the two waits around the gather only
+            # put a number on it (time from this rank's last kernel to the gathered, un-permuted outputs: the collective
+            # itself plus the wait for the slowest rank)
+            torch.cuda.synchronize()
+            tg = time.time()
             if args.backend != 'nccl':          # rehearsal backend: gathers host tensors
                 tok, lens = tok.cpu(), lens.cpu()
             tok, lens = shard.gather_outputs(tok, lens, n_total, order, per_rank)
+            torch.cuda.synchronize()
+            counters['gather_s'] += time.time() - tg
         else:
             tok, lens = shard.unpermute(tok, lens, order)
         return tok.cpu(), lens.cpu()            # final device-to-host copy of the outputs
@@ -287,7 +303,7 @@ def main():
     for _ in range(args.warmup):
         step()
     for k in counters:
-        counters[k] = 0
+        counters[k] = type(counters[k])(0)
     gc.collect()
     gc.disable()      # no collector pauses of the launching thread inside the timed region
     barrier()
@@ -299,10 +315,16 @@ def main():
     barrier()
     dt = time.time() - t0
     gc.enable()
+    rank_ms = gather_ms = None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # every rank's own clock over the timed region and its time in the gather: `value` uses the slowest rank; the
+        # per-rank list shows a straggler, a long gather on the fast ranks is the wait for it
+        t = torch.tensor([dt, counters['gather_s']], dtype=torch.float64, device=device if args.backend == 'nccl' else 'cpu')
+        every = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(every, t)
+        rank_ms = [float(e[0]) / args.steps * 1e3 for e in every]
+        gather_ms = [float(e[1]) / args.steps * 1e3 for e in every]
+        dt = max(float(e[0]) for e in every)
 
     # Separate pass for the roofline figures: HIP events (made before the pass) on the launch stream around every
     # vocabulary-projection and selection launch of one batch.  Not part of `value`.
@@ -346,6 +368,8 @@ def main():
                        'parallelism': 'dp%d (length-sorted sentences dealt round-robin, no in-loop collective, one all-gather of '
                                       'outputs)' % world},
             'output_checksum': checksum(tok_h, lens_h),
+            'rank_ms': rank_ms, 'gather_ms': gather_ms,     # per rank, per step (None for one rank)
+            'host_threads_per_rank': torch.get_num_threads(),
             'timed_path': 'un-instrumented product path (tst_tfm_step_run + tst_select_step_run per decode step)',
         }
         if gemm is not None:

@@ -72,6 +72,27 @@ def test_bench_config5_two_ranks_equal_one_rank(tmp_path):
     assert lines[1]['output_checksum'] == lines[2]['output_checksum']
     assert lines[2]['n_gpus'] == 2 and lines[2]['config']['ranks_seen_by_backend'] == 2 and lines[2]['scaling'] == 'strong'
     assert lines[1]['config']['batches_per_step_rank0'] == 5 and lines[2]['config']['batches_per_step_rank0'] == 3
+    # what makes a scaling curve readable: every rank's own time over the timed region and its time in the gather
+    assert lines[1]['rank_ms'] is None and lines[1]['gather_ms'] is None
+    assert len(lines[2]['rank_ms']) == 2 and len(lines[2]['gather_ms']) == 2
+    assert all(0 < g < r for g, r in zip(lines[2]['gather_ms'], lines[2]['rank_ms']))
+    assert abs(max(lines[2]['rank_ms']) - lines[2]['ms_per_step']) < 1e-6 * lines[2]['ms_per_step']
+    # against the oracle, not only against the one-rank run: 32 sampled sentences of the corpus (the benchmark's model and
+    # corpus, rebuilt here from their seeds) decoded by the canonical CPU oracle equal the sharded run's rows bit for bit
+    import numpy as np
+    import bench as B
+    from oracle import canon as C
+    from oracle import torch_ref as R
+    from tst_amd import synthetic
+    tv = R.synthetic_vocab(B.VOCAB)
+    tmodel = R.synthetic_init(R.Transformer(R.HP(B.HP), tv, tv), 3, 5.5, B.OUT_SCALE, seed=42)
+    pick = np.sort(np.random.RandomState(21).choice(3000, size=32, replace=False))
+    src = synthetic.multi30k_like_sources(3000, B.VOCAB, seed=1240, rows=pick)
+    encs, mask = C.CanonTransformerEncoder(tmodel.encoder, B.HP['n_heads'])(src.numpy())
+    sess = C.CanonTransformerDecoder(tmodel.decoder, B.HP['n_heads']).session(encs, mask, 4, B.MAX_LEN)
+    want = C.beam_decode(sess, 32, 4, B.MAX_LEN, 2, 3, 0.0)[0]
+    tok2, len2 = b[0].numpy(), b[1].numpy()
+    assert [tok2[i, :len2[i]].tolist() for i in pick] == want
 
 
 def test_batch_trimmed_to_its_longest_sentence_decodes_identically():

@@ -36,17 +36,42 @@ def synthetic_state_dict(model, eos_idx=None, eos_bias=0.0, out_scale=1.0, seed=
     return out
 
 
-def multi30k_like_sources(n_sent, vocab_size, seed, pad=1, bos=2, eos=3, mean=13.0, std=4.0, lo=4, hi=40):
+def multi30k_like_lengths(n_sent, seed, mean=13.0, std=4.0, lo=4, hi=40):
+    """Content-token counts of ``multi30k_like_sources(n_sent, ..., seed)`` without building the sentences (int64 [n_sent]);
+    a sentence has two more tokens, BOS and EOS."""
+    rs = np.random.RandomState(seed)
+    return np.clip(np.rint(rs.normal(mean, std, size=n_sent)), lo, hi).astype(np.int64)
+
+
+def multi30k_like_sources(n_sent, vocab_size, seed, pad=1, bos=2, eos=3, mean=13.0, std=4.0, lo=4, hi=40, rows=None,
+                          chunk=65536):
     """Synthetic source batch shaped like Multi30k sentences: ``clamp(round(N(mean, std)), lo, hi)`` content
-    tokens (uniform over the non-special ids) between BOS and EOS, right-padded.  int64 [n_sent, S]."""
+    tokens (uniform over the non-special ids) between BOS and EOS, right-padded.  int64 [n_sent, S].
+    ``rows`` (ascending int64 indices) returns only those sentences of the same corpus, [len(rows), S] in that order: the
+    random stream is drawn chunk by chunk and the other rows are dropped, so a rank of a sharded run never holds the corpus."""
     rs = np.random.RandomState(seed)
     lens = np.clip(np.rint(rs.normal(mean, std, size=n_sent)), lo, hi).astype(np.int64)
     S = int(lens.max()) + 2
-    src = np.full((n_sent, S), pad, dtype=np.int64)
-    body = rs.randint(4, vocab_size, size=(n_sent, S))
     col = np.arange(S)[None, :]
-    src[:, 0] = bos
-    inside = (col >= 1) & (col <= lens[:, None])
-    src[inside] = body[inside]
-    src[np.arange(n_sent), lens + 1] = eos
+    if rows is None:
+        keep_all, rows = True, np.arange(n_sent, dtype=np.int64)
+    else:
+        keep_all, rows = False, np.asarray(rows, dtype=np.int64)
+        if rows.size and (np.any(np.diff(rows) <= 0) or rows[0] < 0 or rows[-1] >= n_sent):
+            raise ValueError('rows must be ascending indices into the corpus')
+    src = np.full((rows.size, S), pad, dtype=np.int64)
+    done = 0
+    for c0 in range(0, n_sent, n_sent if keep_all else chunk):
+        c1 = n_sent if keep_all else min(n_sent, c0 + chunk)
+        body = rs.randint(4, vocab_size, size=(c1 - c0, S))     # the stream of the whole corpus, a chunk at a time
+        hi_i = np.searchsorted(rows, c1)
+        mine = rows[done:hi_i]
+        if mine.size:
+            ln = lens[mine]
+            inside = (col >= 1) & (col <= ln[:, None])
+            part = src[done:hi_i]
+            part[:, 0] = bos
+            part[inside] = body[mine - c0][inside]
+            part[np.arange(mine.size), ln + 1] = eos
+        done = hi_i
     return torch.from_numpy(src)
