@@ -141,6 +141,38 @@ def test_config3_gru_full_batch_sample_vs_oracle(T):
         assert len(set(lens.tolist())) > 5 and lens.max() <= ML + 1
 
 
+@pytest.mark.parametrize('eos_bias', [1.0, 0.1])
+def test_config3_gru_v32000_full_batch_sample_vs_oracle(T, eos_bias):
+    """BASELINE config 3, the 32000-word variant (the K = 1024 vocabulary projection dominates it): 8192 sentences, greedy and
+    beam 4, max_len 100; 48 sampled sentences equal the oracle bit for bit (tokens and beam scores).  Two EOS biases: the one
+    the throughput figures are quoted on (short sentences) and one that keeps sentences alive for tens of steps."""
+    from tst_amd import synthetic
+    vocab = T.Vocab.synthetic(V, extra=('|',))
+    model = T.RNNDecoder(1024, 1024, vocab)
+    model.load_state_dict(synthetic.synthetic_state_dict(model, vocab.stoi['|'], eos_bias, 2.0, seed=42))
+    tv = R.synthetic_vocab(V, extra=('|',))
+    tmodel = R.synthetic_init(R.RNNDecoder(1024, 1024, tv), tv.stoi['|'], eos_bias, 2.0, seed=42)
+    z = torch.randn((8192, 1024), generator=torch.Generator().manual_seed(1237))
+    n_pick = 48 if eos_bias > 0.5 else 12
+    pick = np.sort(np.random.RandomState(13).choice(8192, size=n_pick, replace=False))
+    eos = vocab.stoi['|']
+    ML = 100
+    for beam in (1, 4):
+        st = T.InferenceState({'model': model, 'inputs': z.cuda(), 'vocab': vocab, 'max_len': ML, 'eos_token': '|',
+                               'beam_size': beam})
+        tok, lens, score = (x.cpu().numpy() for x in st.decode_packed())
+        del st
+        torch.cuda.empty_cache()
+        sess = C.CanonGRUDecoder(tmodel).session(z[pick].numpy(), beam)
+        if beam == 1:
+            want = C.greedy_decode(sess, n_pick, ML, 2, eos)[0]
+        else:
+            want, wscore, _, _ = C.beam_decode(sess, n_pick, beam, ML, 2, eos)
+            assert np.array_equal(score[pick], wscore)
+        assert rows_as_lists(tok, lens, pick) == want
+        assert len(set(lens.tolist())) > 2 and lens.max() <= ML + 1
+
+
 def test_config4_lm_sizes_fp32_sample_and_bf16_properties(T):
     """BASELINE config 4 sizes (model_size 512, 6 layers, 8 heads, d_ff 2048, V = 32000, beam 8, max_len 50).  fp32: 6
     sampled sentences of a 2048-sentence batch equal the oracle bit for bit (tokens and scores).  bf16 (tolerance-checked
