@@ -34,7 +34,9 @@ extern "C" {
  * tst_greedy_retire_compact; 102 = 101 + tst_retire_compact_noalloc;
  * 103 = 102 + tst_gru_cell_fused_f32, tst_gru_cell_fused_ok, TST_STEP_FUSED_CELL;
  * 104 = 103 + tst_gemm_dma_f32, tst_layernorm_t_f32, tst_tfm_step.ht / ld_ht, tst_attn_cross_mfma_f32,
- * tst_select_step.n_sent_dev, tst_pack_sources, tst_scatter_rows_f32 (additions only). */
+ * tst_select_step.n_sent_dev, tst_pack_sources, tst_scatter_rows_f32;
+ * 105 = 104 + tst_vocab_stats_ok, tst_vocabproj_stats_bf16, tst_topk_from_stats_bf16, tst_tfm_step.part / n_slices,
+ * tst_select_step.part / n_slices / stats_k (additions only). */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
@@ -232,6 +234,27 @@ int tst_sample_rows_bf16(const void* logits, int64_t ld, int64_t R, int64_t V, f
 int tst_logsoftmax_topk_bf16(const void* logits, int64_t ld, int64_t R, int64_t V, int64_t k, float* top_val,
                              int32_t* top_idx, float* lse, void* stream);
 
+/* The vocabulary projection of a beam-search step with the first half of the selection pass in its epilogue: C as
+ * tst_gemm_mfma_bf16 (bf16 result, bias, no activation, no residual), and for every row and every slice of 64 columns of it
+ * the slice's largest STORED (bf16-rounded) logit and the sum of exp(logit - largest) over the slice.  Together they replace
+ * nn.Linear d_model -> V followed by the first pass of log_softmax / topk over the [rows, V] logits
+ * (/root/reference/src/inference.py:132-145 picks tokens from those logits; the reference has no beam search).
+ * part: [ceil(M / 32)][n_slices][64] floats, n_slices = ceil(N / 64): block b, slice s holds the maxima of rows 32 b .. 32 b + 31
+ * in its first 32 floats and their sums in the last 32 (entries of rows >= M are unspecified).
+ * Only for the shapes tst_vocab_stats_ok accepts (those the persistent 256 x 256 kernel serves: 4096 <= N <= 32768, N % 8 == 0,
+ * K % 32 == 0, K >= 96, at least 256 tiles of 256 x 256); TST_ERR_UNSUPPORTED otherwise.  C is bit-identical to
+ * tst_gemm_mfma_bf16's. */
+int tst_vocab_stats_ok(int64_t M, int64_t N, int64_t K);
+int tst_vocabproj_stats_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
+                             int64_t M, int64_t N, int64_t K, float* part, int64_t n_slices, void* stream);
+
+/* tst_logsoftmax_topk_bf16 from those statistics: lse[r] = M + log(sum_s sum_s * exp(max_s - M)), M = max_s max_s; the k
+ * largest logits are found in the slices whose maximum reaches the k-th largest slice maximum (those slices are re-read from
+ * `logits`, everything else of the row is not).  top_val / top_idx equal tst_logsoftmax_topk_bf16's exactly (a selection);
+ * lse agrees with it to fp32 rounding (another summation order).  V % 8 == 0, ld % 8 == 0, n_slices = ceil(V / 64) <= 512. */
+int tst_topk_from_stats_bf16(const void* logits, int64_t ld, const float* part, int64_t n_slices, int64_t R, int64_t V,
+                             int64_t k, float* top_val, int32_t* top_idx, float* lse, void* stream);
+
 /* Decode-loop state.  All arrays are device memory owned by the caller; "cur" arrays are read, "nxt"
  * arrays are written (ping-pong).  Rows of one sentence are contiguous (k rows per sentence).
  *   hist  [rows][T+1] int32  tokens so far, BOS first          anc [rows][T] int32  cache row per position
@@ -352,6 +375,10 @@ typedef struct tst_tfm_step {
                                step has at least TST_DMA_MIN_ROWS rows, the final LayerNorm writes here (tst_layernorm_t_f32)
                                and the vocabulary projection is tst_gemm_dma_f32; h is then not written.  Same logits. */
     int64_t ld_ht;          /* >= slab_rows rounded up to a multiple of 128 */
+    float* part;            /* bf16 only, optional: [ceil(slab_rows / 32)][n_slices][64] statistics of the logits.  When set and
+                               tst_vocab_stats_ok(rows, V, d), the vocabulary projection is tst_vocabproj_stats_bf16 and
+                               tst_select_step_run (given the same buffer) reads them instead of the whole rows.  Same logits. */
+    int64_t n_slices;       /* ceil(V / 64) */
 } tst_tfm_step;
 #define TST_DMA_MIN_ROWS 2048
 
@@ -413,6 +440,11 @@ typedef struct tst_select_step {
                                     argument of tst_select_step_run is only an upper bound (a caller that launches a step
                                     before it has read the previous step's n_alive).  Sentences beyond it are ignored; the rows
                                     the caller stepped for them are wasted work, nothing else.  Must not alias n_alive. */
+    const float* part;           /* NULL, or the statistics tst_tfm_step_run leaves beside bf16 logits (tst_tfm_step.part): for
+                                    k > 1 and a step of a shape tst_vocab_stats_ok(rows, V, stats_k) accepts, the selection is
+                                    tst_topk_from_stats_bf16 instead of tst_logsoftmax_topk_bf16 */
+    int64_t n_slices;            /* ceil(V / 64) */
+    int64_t stats_k;             /* inner dimension of the vocabulary projection that wrote `part` (d_model) */
 } tst_select_step;
 
 int tst_select_step_run(const tst_select_step* s, const tst_rows* cur, const tst_rows* nxt, int64_t n_sent, int64_t k_in,

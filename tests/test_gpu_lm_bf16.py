@@ -130,6 +130,120 @@ def test_selection_kernels_on_bf16_logits(K, V, ld, k):
     assert np.array_equal(tok.cpu().numpy(), C.sample_rows(xf, 0.7, 5, 2, np.arange(R_, dtype=np.int32)))
 
 
+def _stats_from_logits(xf, n_rows_pad):
+    """Per-slice statistics of bf16 logits (as floats) in the layout of tst_vocabproj_stats_bf16, computed in float64."""
+    R_, V = xf.shape
+    ns = (V + 63) // 64
+    pad = np.full((n_rows_pad, ns * 64), -np.inf)
+    pad[:R_, :V] = xf
+    sl = pad.reshape(n_rows_pad, ns, 64)
+    mx = sl.max(axis=2)
+    with np.errstate(invalid='ignore'):
+        sm = np.where(np.isfinite(mx), np.exp(sl - np.where(np.isfinite(mx), mx, 0.0)[:, :, None]).sum(axis=2), 0.0)
+    mx = np.where(np.isfinite(mx), mx, 0.0)
+    part = np.stack([mx.reshape(-1, 32, ns).transpose(0, 2, 1), sm.reshape(-1, 32, ns).transpose(0, 2, 1)], axis=2)  # [blk, ns, 2, 32]
+    return np.ascontiguousarray(part.reshape(-1, ns, 64)).astype(np.float32)
+
+
+@pytest.mark.parametrize('M,N,Kd', [(700, 32000, 512), (4100, 4104, 96), (65, 32000 + 8 * 5, 128)])
+def test_vocabproj_stats_epilogue_and_topk_from_stats(K, M, N, Kd):
+    """The vocabulary projection with the selection statistics in its epilogue: logits bit-identical to the plain bf16
+    GEMM, slice maxima exact, slice sums to fp32 rounding; the selection from the statistics equals the selection over the
+    whole rows (indices and values exactly, lse within the tolerance of test_selection_kernels_on_bf16_logits)."""
+    g = torch.Generator(device='cuda').manual_seed(M + N)
+    if not K.vocab_stats_ok(M, N, Kd):
+        assert M == 65                      # too few tiles for the persistent kernel: the entry point must refuse
+        a = bf(torch.randn((M, Kd), device='cuda', generator=g))
+        w = bf(torch.randn((N, Kd), device='cuda', generator=g))
+        part = torch.empty(((M + 31) // 32, (N + 63) // 64, 64), device='cuda')
+        from tst_amd import _lib
+        with pytest.raises(_lib.TstError):
+            K.vocabproj_stats(a, w, torch.zeros(N, device='cuda'), torch.empty((M, N), device='cuda', dtype=torch.bfloat16), part, M)
+        return
+    a = bf(torch.randn((M, Kd), device='cuda', generator=g))
+    w = bf(torch.randn((N, Kd), device='cuda', generator=g) * (3.0 / Kd ** 0.5))
+    b = torch.randn(N, device='cuda', generator=g)
+    ld = (N + 7) // 8 * 8
+    want = torch.full((M + 5, ld), 7.0, device='cuda', dtype=torch.bfloat16)
+    got = torch.full((M + 5, ld), 7.0, device='cuda', dtype=torch.bfloat16)
+    nblk, ns = (M + 31) // 32, (N + 63) // 64
+    part = torch.full((nblk, ns, 64), float('nan'), device='cuda')
+    K.gemm_bf16(a, w, b, want, M, n_cols=N)
+    K.vocabproj_stats(a, w, b, got, part, M, n_cols=N)
+    assert torch.equal(got, want)                                                   # the same logits, nothing outside [M, N] written
+    xf = got[:M, :N].float().cpu().numpy()
+    ref = _stats_from_logits(xf.astype(np.float64), nblk * 32)
+    p = part.cpu().numpy().reshape(nblk, ns, 2, 32)
+    rows_ok = (np.arange(nblk * 32) < M).reshape(nblk, 1, 32)
+    r = ref.reshape(nblk, ns, 2, 32)
+    assert np.array_equal(np.where(rows_ok, p[:, :, 0], 0), np.where(rows_ok, r[:, :, 0], 0))          # maxima: exact
+    assert np.allclose(np.where(rows_ok, p[:, :, 1], 1), np.where(rows_ok, r[:, :, 1], 1), rtol=2e-6, atol=0)
+    for k in (1, 4, 8):
+        tv = torch.empty((M, k), device='cuda')
+        ti = torch.empty((M, k), dtype=torch.int32, device='cuda')
+        lse = torch.empty(M, device='cuda')
+        K.topk_from_stats(got, part, M, N, k, tv, ti, lse)
+        wv, wi, _ = C.logsoftmax_topk(xf, k)
+        assert np.array_equal(ti.cpu().numpy(), wi) and np.array_equal(tv.cpu().numpy(), wv)
+        exact = torch.logsumexp(got[:M, :N].double(), dim=-1).cpu().numpy()
+        assert np.abs(lse.cpu().numpy() - exact).max() <= 2e-6 * np.abs(exact).max() + 1e-6
+
+
+def test_topk_from_stats_with_many_equal_values(K):
+    """Rows of few distinct values (bf16 logits tie often; here on purpose): all-equal rows, rows whose top values fill many
+    slices, a row with its maximum in the last column.  More slices / candidates than the kernel's lists hold: the whole-row
+    rounds must give the same selection (value descending, index ascending)."""
+    V, R_ = 8192, 70
+    rs = np.random.RandomState(4)
+    x = np.zeros((R_, V), dtype=np.float32)
+    x[1] = rs.randint(0, 2, size=V)                       # half the row ties at the maximum
+    x[2] = rs.randint(0, 4, size=V) * 0.5
+    x[3, -1] = 5.0
+    x[4] = -3.0
+    x[5, ::64] = 2.0                                      # one maximal element in every slice
+    x[6:] = np.round(rs.standard_normal((R_ - 6, V)) * 2) * 0.5
+    xt = torch.from_numpy(x).cuda().to(torch.bfloat16)
+    part = torch.from_numpy(_stats_from_logits(x.astype(np.float64), (R_ + 31) // 32 * 32)).cuda()
+    for k in (1, 3, 8):
+        tv = torch.empty((R_, k), device='cuda')
+        ti = torch.empty((R_, k), dtype=torch.int32, device='cuda')
+        lse = torch.empty(R_, device='cuda')
+        K.topk_from_stats(xt, part, R_, V, k, tv, ti, lse)
+        wv, wi, _ = C.logsoftmax_topk(x, k)
+        assert np.array_equal(ti.cpu().numpy(), wi) and np.array_equal(tv.cpu().numpy(), wv)
+        exact = torch.logsumexp(torch.from_numpy(x).double(), dim=-1).numpy()
+        assert np.abs(lse.cpu().numpy() - exact).max() <= 2e-6 * np.abs(exact).max() + 1e-6
+
+
+def test_lm_bf16_beam_decode_same_with_and_without_vocab_statistics(T, monkeypatch):
+    lm_mod = __import__('importlib').import_module('text-style-transfer_amd.lm')
+    """End to end at a size whose steps take the statistics route (4096 sentences x beam 8, V = 32000 is config 4's shape at
+    half the batch; here a smaller model, 2 layers): the beam-search outputs with the statistics (TST_VOCAB_STATS=1) and with the two
+    plain kernels (the default) are the same sequences; scores agree to fp32 rounding of the log-sum-exp."""
+    hp = dict(model_size=128, n_layers=2, n_heads=4, d_ff=256, pe_max_len=24)
+    Vb, B = 32000, 1024
+    vocab = T.Vocab.synthetic(Vb)
+    from tst_amd import synthetic
+    lm = T.TransformerLM(T.HP(hp), vocab, dtype='bf16')
+    lm.load_state_dict(synthetic.synthetic_state_dict(lm, 3, 5.0, 2.0, seed=42))
+    z = (0.3 * torch.randn((B, 128), generator=torch.Generator().manual_seed(5))).cuda()
+
+    def run():
+        st = T.InferenceState({'model': lm, 'inputs': z, 'vocab': vocab, 'max_len': 12, 'beam_size': 8})
+        tok, lens, score = st.decode_packed()
+        return tok.cpu().numpy(), lens.cpu().numpy(), score.cpu().numpy(), st.loop.s.stats is not None
+
+    monkeypatch.setattr(lm_mod, 'VOCAB_STATS', True)
+    tok_a, len_a, sc_a, used = run()
+    assert used
+    monkeypatch.setattr(lm_mod, 'VOCAB_STATS', False)
+    tok_b, len_b, sc_b, used = run()
+    assert not used
+    same = float(np.mean((len_a == len_b) & (tok_a == tok_b).all(axis=1)))
+    assert same >= 0.995, same          # a different summation order of lse can flip a tie between nearly equal beam scores
+    assert np.allclose(sc_a[(tok_a == tok_b).all(axis=1)], sc_b[(tok_a == tok_b).all(axis=1)], rtol=1e-5, atol=1e-5)
+
+
 def lm_pair(T, cfg, dtype='fp32'):
     tmodel, _ = torch_model_for(cfg)
     vocab = T.Vocab.synthetic(cfg['V'])

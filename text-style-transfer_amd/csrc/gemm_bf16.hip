@@ -452,18 +452,25 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_bf16_dma_kernel(const __b
 // after a partial tile (fewer stores than NSTORE) the stricter count without stores is used.
 // The bf16 image of the epilogue is a region of its own behind the stages (32 rows per wave at a time), written
 // and read with inline assembly: LDS accesses the compiler knows of would be ordered behind every pending DMA.
-template <int NST, bool RELU>
+// STATS (vocabulary projection feeding a beam search): for every row and every slice of 64 columns the epilogue also emits
+// the slice's largest logit and the sum of exp(logit - largest), both taken from the bf16-ROUNDED values that are stored, so
+// that the selection pass needs the row's 2 * ceil(N / 64) partial values and the few slices that can hold a top-k element
+// instead of the whole row.  A wave's 64 columns of a row sit 32 and 32 in the two lanes (h = 0, 1) of that row: one exchange
+// across the wave halves per reduction.  Layout of `part`: [row block of 32][slice][max of rows 0..31 | sum of rows 0..31]
+// floats, so that a wave stores two contiguous 128-byte pieces per slice (one instruction, lanes h = 0: max, h = 1: sum).
+template <int NST, bool RELU, bool STATS>
 __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(const __bf16* __restrict__ A, int64_t lda,
                                                                 const __bf16* __restrict__ W, int64_t ldw,
                                                                 const float* __restrict__ bias, __bf16* __restrict__ Cout,
-                                                                int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
+                                                                int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n,
+                                                                float* __restrict__ part, int n_slices) {
     constexpr int WVN = 4, WTM = 4, WTN = 2, NWV = 8, TM = 256, TN = 256, GM = 8;
     constexpr int STAGE = (TM + TN) * 64;
     constexpr int OUT_LD = 16 + 64 * WTN;                // bytes per row of a wave's output image
     constexpr int IMG = 32 * OUT_LD;                     // 32 rows at a time
     constexpr int BIAS_OFF = NST * STAGE, IMG_OFF = BIAS_OFF + NWV * 1024;
     constexpr int NA = TM / (16 * NWV), NW = TN / (16 * NWV), NDMA = NA + NW;
-    constexpr int NSTORE = WTM * 4;                      // global stores of a wave per full tile
+    constexpr int NSTORE = WTM * (STATS ? 5 : 4);        // global stores of a wave per full tile
     static_assert(NDMA * (NST - 1) + NSTORE < 64, "vmcnt is a 6-bit counter");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[IMG_OFF + NWV * IMG];
 
@@ -620,6 +627,8 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(const __bf16* __
         const int gcol = tn0 + wn * 64 + (lane & 7) * 8;
 #pragma unroll
         for (int i = 0; i < WTM; ++i) {
+            float wv[STATS ? 16 * WTN : 1];              // the lane's 32 values of its row as stored (bf16, widened)
+            float mx = -INFINITY;
 #pragma unroll
             for (int j = 0; j < WTN; ++j)
 #pragma unroll
@@ -631,12 +640,30 @@ __global__ __launch_bounds__(512) void gemm_bf16_persist_kernel(const __bf16* __
                         float v = acc[i][j][4 * g + e];
                         if (RELU) v = v > 0.0f ? v : 0.0f;
                         cv.b[e] = (__bf16)v;
+                        if (STATS) {
+                            float w = (float)cv.b[e];
+                            if (!full && tn0 + wn * 64 + 32 * j + 8 * g + 4 * h + e >= N) w = -INFINITY;   // not a column of C
+                            wv[16 * j + 4 * g + e] = w;
+                            mx = fmaxf(mx, w);
+                        }
                     }
                     asm volatile("ds_write_b64 %0, %1" ::"v"(wr + j * 64 + 16 * g), "v"(cv.u) : "memory");
                 }
             u32x4 o[4];
 #pragma unroll
             for (int p = 0; p < 4; ++p) asm volatile("ds_read_b128 %0, %1" : "=v"(o[p]) : "v"(rd + p * 8 * OUT_LD) : "memory");
+            if (STATS) {
+                mx = fmaxf(mx, lane_xor<32>(mx));
+                float sum = 0.0f;
+#pragma unroll
+                for (int q = 0; q < 16 * WTN; ++q) sum += __builtin_amdgcn_exp2f((wv[q] - mx) * 1.44269504088896341f);
+                sum += lane_xor<32>(sum);
+                const int blk = (tm0 + wm * 128 + i * 32) >> 5, slice = (tn0 >> 6) + wn;
+                float* dst = part + ((int64_t)blk * n_slices + slice) * 64 + lane;     // lanes 0..31: max, 32..63: sum
+                const float val = h ? sum : mx;
+                if (full) __builtin_nontemporal_store(val, dst);
+                else if (blk * 32 < M && slice < n_slices) __builtin_nontemporal_store(val, dst);
+            }
             lds_wait();
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
@@ -712,11 +739,11 @@ extern "C" int tst_gemm_mfma_bf16(const void* A, int64_t lda, const void* W, int
             // one workgroup per CU (the kernel's LDS allows no second one), a multiple of 8 so that every XCD has the same slots
             const dim3 gp(256);
             if (act == 1)
-                hipLaunchKernelGGL((gemm_bf16_persist_kernel<3, true>), gp, dim3(512), 0, st, (const __bf16*)A, lda, (const __bf16*)W, ldw,
-                                   bias, (__bf16*)C, ldc, (int)M, (int)N, (int)K, (int)tm, (int)tn);
+                hipLaunchKernelGGL((gemm_bf16_persist_kernel<3, true, false>), gp, dim3(512), 0, st, (const __bf16*)A, lda, (const __bf16*)W, ldw,
+                                   bias, (__bf16*)C, ldc, (int)M, (int)N, (int)K, (int)tm, (int)tn, nullptr, 0);
             else
-                hipLaunchKernelGGL((gemm_bf16_persist_kernel<3, false>), gp, dim3(512), 0, st, (const __bf16*)A, lda, (const __bf16*)W, ldw,
-                                   bias, (__bf16*)C, ldc, (int)M, (int)N, (int)K, (int)tm, (int)tn);
+                hipLaunchKernelGGL((gemm_bf16_persist_kernel<3, false, false>), gp, dim3(512), 0, st, (const __bf16*)A, lda, (const __bf16*)W, ldw,
+                                   bias, (__bf16*)C, ldc, (int)M, (int)N, (int)K, (int)tm, (int)tn, nullptr, 0);
             return tst_after_launch("tst_gemm_mfma_bf16");
         }
 #define TST_BF16_DMA(OB, HR, RL)                                                                                      \
@@ -762,4 +789,30 @@ extern "C" int tst_gemm_mfma_bf16(const void* A, int64_t lda, const void* W, int
     }
 #undef TST_BF16_LAUNCH
     return tst_after_launch("tst_gemm_mfma_bf16");
+}
+
+
+// The shapes for which the vocabulary projection can emit its per-slice statistics: those that tst_gemm_mfma_bf16 runs on the
+// persistent 256 x 256 kernel (a bf16 result of at least 4096 columns and 256 tiles, K a multiple of 32 and at least 96)
+// and whose rows have at most 512 slices of 64 columns (what tst_topk_from_stats_bf16 holds per row).
+extern "C" int tst_vocab_stats_ok(int64_t M, int64_t N, int64_t K) {
+    if (M <= 0 || N < 4096 || N > 32768 || N % 8 != 0 || K % DK != 0 || K / DK < 3 || M >= (1ll << 31) || N >= (1ll << 31) || K >= (1ll << 31)) return 0;
+    return ((M + 255) / 256) * ((N + 255) / 256) >= 256 ? 1 : 0;
+}
+
+extern "C" int tst_vocabproj_stats_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
+                                        int64_t M, int64_t N, int64_t K, float* part, int64_t n_slices, void* stream) {
+    TST_REQUIRE(A && W && C && part, TST_ERR_ARG, "tst_vocabproj_stats_bf16: null pointer");
+    TST_REQUIRE(tst_vocab_stats_ok(M, N, K), TST_ERR_UNSUPPORTED,
+                "tst_vocabproj_stats_bf16: M=%lld N=%lld K=%lld is not a shape of the persistent kernel (tst_vocab_stats_ok)", (long long)M,
+                (long long)N, (long long)K);
+    TST_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldc % 8 == 0 && lda >= K && ldw >= K && ldc >= N, TST_ERR_ARG,
+                "tst_vocabproj_stats_bf16: lda, ldw, ldc must be multiples of 8, lda >= K, ldw >= K, ldc >= N");
+    TST_REQUIRE(tst_aligned16(A) && tst_aligned16(W) && tst_aligned16(C) && tst_aligned16(bias) && tst_aligned16(part), TST_ERR_ARG,
+                "tst_vocabproj_stats_bf16: A, W, C, bias, part must be 16-byte aligned");
+    TST_REQUIRE(n_slices == (N + 63) / 64, TST_ERR_ARG, "tst_vocabproj_stats_bf16: n_slices must be ceil(N / 64)");
+    const int64_t tm = (M + 255) / 256, tn = (N + 255) / 256;
+    hipLaunchKernelGGL((gemm_bf16_persist_kernel<3, false, true>), dim3(256), dim3(512), 0, (hipStream_t)stream, (const __bf16*)A, lda,
+                       (const __bf16*)W, ldw, bias, (__bf16*)C, ldc, (int)M, (int)N, (int)K, (int)tm, (int)tn, part, (int)n_slices);
+    return tst_after_launch("tst_vocabproj_stats_bf16");
 }

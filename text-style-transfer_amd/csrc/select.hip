@@ -310,6 +310,140 @@ __global__ __launch_bounds__(256) void logsoftmax_topk_kernel(const T* __restric
     }
 }
 
+// Log-sum-exp + top K of bf16 logits whose vocabulary projection has already reduced every slice of 64 columns to (largest
+// value, sum of exp(value - largest)) in its epilogue (tst_vocabproj_stats_bf16): a row then costs 8 * n_slices bytes of
+// statistics plus the few slices that can hold one of its K largest elements, instead of its 2 * V bytes.
+// One workgroup of 8 waves per block of 32 rows (the unit of the statistics' layout): the block's statistics are staged
+// into LDS transposed to [row][slice], then every wave finishes 4 rows on its own (no further workgroup barrier):
+//   M = max of the slice maxima;  lse = M + log(sum over slices of sum_s * exp(max_s - M));
+//   tau = the K-th largest slice maximum: at least K elements are >= tau and they sit in slices whose maximum is >= tau;
+//   those slices are re-read from the logits (128 bytes each), their elements >= tau go to a list, from which K rounds of
+//   wave arg-max (value descending, index ascending) pick the result, the same selection as logsoftmax_topk_kernel.
+// Many equal values can overflow the lists; the wave then runs its K rounds over the whole row.
+constexpr int STAT_ROWS = 32, STAT_NSMAX = 512, STAT_LD = STAT_NSMAX + 1, STAT_HOT = 64, STAT_CAND = 256;
+
+template <int K>
+__global__ __launch_bounds__(512) void topk_from_stats_kernel(const __bf16* __restrict__ x, int64_t ld, int V,
+                                                              const float* __restrict__ part, int n_slices, int R,
+                                                              float* __restrict__ top_val, int32_t* __restrict__ top_idx,
+                                                              float* __restrict__ lse) {
+    __shared__ float sm[STAT_ROWS * STAT_LD], ss[STAT_ROWS * STAT_LD];
+    __shared__ int hot[8][STAT_HOT];
+    __shared__ float cand_v[8][STAT_CAND];
+    __shared__ int cand_i[8][STAT_CAND];
+    __shared__ int cand_n[8];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int64_t r0 = (int64_t)blockIdx.x * STAT_ROWS;
+    // stage: float4 number q of the block holds rows 4 (q % 16) .. + 3 (first 32: maxima, then sums) of slice q / 16
+    const float4* src = reinterpret_cast<const float4*>(part + (int64_t)blockIdx.x * n_slices * 64);
+    for (int q = t; q < n_slices * 16; q += 512) {
+        const float4 v = src[q];
+        const int sl = q >> 4, c = (q & 15) * 4;
+        float* dst = (c < 32 ? sm : ss) + (c & 31) * STAT_LD + sl;
+        dst[0] = v.x; dst[STAT_LD] = v.y; dst[2 * STAT_LD] = v.z; dst[3 * STAT_LD] = v.w;
+    }
+    __syncthreads();
+    constexpr int NJ = STAT_NSMAX / 64;
+    for (int rr = 0; rr < STAT_ROWS / 8; ++rr) {
+        const int lr = wave * (STAT_ROWS / 8) + rr;
+        const int64_t r = r0 + lr;
+        if (r >= R) break;                                   // wave-uniform
+        const __bf16* xr = x + r * ld;
+        float mg[NJ], m0[NJ];
+        float lm = -INFINITY;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int sl = lane + 64 * j;
+            mg[j] = sl < n_slices ? sm[lr * STAT_LD + sl] : -INFINITY;
+            m0[j] = mg[j];
+            lm = fmaxf(lm, mg[j]);
+        }
+        const float M = wave_max(lm);
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int sl = lane + 64 * j;
+            if (sl < n_slices) acc += ss[lr * STAT_LD + sl] * __builtin_amdgcn_exp2f((mg[j] - M) * 1.44269504088896341f);
+        }
+        const float total = wave_sum_butterfly(acc);
+        if (lane == 0) lse[r] = M + d_log(total);
+        // K-th largest slice maximum (ties between slices: lower slice first)
+        float tau = -INFINITY;
+        for (int o = 0; o < K; ++o) {
+            float v = mg[0];
+            int id = lane;
+#pragma unroll
+            for (int j = 1; j < NJ; ++j)
+                if (mg[j] > v) { v = mg[j]; id = lane + 64 * j; }
+            const int mine = id;
+            wave_argmax(v, id);
+            tau = v;
+            if (id == mine) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    if (id == lane + 64 * j) mg[j] = -INFINITY;
+            }
+        }
+        int nh = 0;   // slices whose maximum reaches tau
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const bool is_hot = m0[j] >= tau && lane + 64 * j < n_slices;
+            const unsigned long long bal = __ballot(is_hot);
+            const int at = nh + __popcll(bal & ((1ull << lane) - 1ull));
+            if (is_hot && at < STAT_HOT) hot[wave][at] = lane + 64 * j;
+            nh += __popcll(bal);
+        }
+        if (lane == 0) cand_n[wave] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        bool overflow = nh > STAT_HOT;
+        if (!overflow) {
+            // 8 lanes per hot slice, 16 bytes (8 elements) each
+            for (int it = lane; it < nh * 8; it += 64) {
+                const int c = hot[wave][it >> 3] * 8 + (it & 7);     // 16-byte chunk of the row
+                float e[8];
+                load_chunk(xr, c, V, true, e);
+#pragma unroll
+                for (int q = 0; q < 8; ++q)
+                    if (e[q] >= tau && 8 * c + q < V) {
+                        const int at = atomicAdd(&cand_n[wave], 1);
+                        if (at < STAT_CAND) { cand_v[wave][at] = e[q]; cand_i[wave][at] = 8 * c + q; }
+                    }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            overflow = cand_n[wave] > STAT_CAND;
+        }
+        if (!overflow) {
+            const int ncand = cand_n[wave];
+            for (int o = 0; o < K; ++o) {
+                float bv = -INFINITY;
+                int bi = INT_MAX, be = -1;
+                for (int e = lane; e < ncand; e += 64)
+                    if (better(cand_v[wave][e], cand_i[wave][e], bv, bi)) { bv = cand_v[wave][e]; bi = cand_i[wave][e]; be = e; }
+                const int mine = bi;
+                wave_argmax(bv, bi);
+                if (be >= 0 && bi == mine) { cand_v[wave][be] = -INFINITY; cand_i[wave][be] = INT_MAX; }
+                if (lane == 0) { top_val[r * K + o] = bv; top_idx[r * K + o] = bi == INT_MAX ? -1 : bi; }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            }
+        } else {
+            float lastv = INFINITY;
+            int lasti = -1;
+            for (int o = 0; o < K; ++o) {
+                float bv = -INFINITY;
+                int bi = INT_MAX;
+                for (int id = lane; id < V; id += 64) {
+                    const float e = elem_at(xr, id);
+                    const bool after = e < lastv || (e == lastv && id > lasti);
+                    if (after && better(e, id, bv, bi)) { bv = e; bi = id; }
+                }
+                wave_argmax(bv, bi);
+                lastv = bv; lasti = bi;
+                if (lane == 0) { top_val[r * K + o] = bv; top_idx[r * K + o] = bi == INT_MAX ? -1 : bi; }
+            }
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void greedy_select_kernel(const int32_t* __restrict__ am, int64_t n, int32_t eos,
                                                             int32_t* parent, int32_t* tok, float* score, int32_t* fin,
                                                             int32_t* nemit, tst_rows cur) {
@@ -671,6 +805,34 @@ extern "C" int tst_logsoftmax_topk_f32(const float* logits, int64_t ld, int64_t 
 extern "C" int tst_logsoftmax_topk_bf16(const void* logits, int64_t ld, int64_t R, int64_t V, int64_t k, float* top_val,
                                         int32_t* top_idx, float* lse, void* stream) {
     return topk_entry<__bf16>((const __bf16*)logits, ld, R, V, k, top_val, top_idx, lse, stream, "tst_logsoftmax_topk_bf16");
+}
+
+extern "C" int tst_topk_from_stats_bf16(const void* logits, int64_t ld, const float* part, int64_t n_slices, int64_t R, int64_t V,
+                                        int64_t k, float* top_val, int32_t* top_idx, float* lse, void* stream) {
+    TST_REQUIRE(logits && part && top_val && top_idx && lse, TST_ERR_ARG, "tst_topk_from_stats_bf16: null pointer");
+    TST_REQUIRE(R >= 0 && R < (1ll << 31) && V > 0 && ld >= V && k >= 1 && k <= 8 && k <= V, TST_ERR_ARG, "tst_topk_from_stats_bf16: bad sizes");
+    TST_REQUIRE(V % 8 == 0 && ld % 8 == 0 && tst_aligned16(logits) && tst_aligned16(part), TST_ERR_ARG,
+                "tst_topk_from_stats_bf16: V and ld must be multiples of 8, logits and part 16-byte aligned");
+    TST_REQUIRE(n_slices == (V + 63) / 64, TST_ERR_ARG, "tst_topk_from_stats_bf16: n_slices must be ceil(V / 64)");
+    TST_REQUIRE(n_slices <= STAT_NSMAX, TST_ERR_UNSUPPORTED, "tst_topk_from_stats_bf16: at most %d slices (V <= %d)", STAT_NSMAX,
+                STAT_NSMAX * 64);
+    if (R == 0) return TST_OK;
+    const dim3 grid((unsigned)((R + STAT_ROWS - 1) / STAT_ROWS));
+#define TST_STATS_TOPK(KK)                                                                                                        \
+    hipLaunchKernelGGL(topk_from_stats_kernel<KK>, grid, dim3(512), 0, (hipStream_t)stream, (const __bf16*)logits, ld, (int)V, part, \
+                       (int)n_slices, (int)R, top_val, top_idx, lse)
+    switch (k) {
+        case 1: TST_STATS_TOPK(1); break;
+        case 2: TST_STATS_TOPK(2); break;
+        case 3: TST_STATS_TOPK(3); break;
+        case 4: TST_STATS_TOPK(4); break;
+        case 5: TST_STATS_TOPK(5); break;
+        case 6: TST_STATS_TOPK(6); break;
+        case 7: TST_STATS_TOPK(7); break;
+        default: TST_STATS_TOPK(8); break;
+    }
+#undef TST_STATS_TOPK
+    return tst_after_launch("tst_topk_from_stats_bf16");
 }
 
 extern "C" int tst_greedy_select(const int32_t* argmax_tok, int64_t n_rows, int32_t eos, int32_t* sel_parent,

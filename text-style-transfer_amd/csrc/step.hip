@@ -111,6 +111,10 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
         if (dma_vocab)
             TST_TRY(tst_gemm_dma_f32(m->ht, m->ld_ht, (const float*)m->wout, m->ld_wout, m->bout, (float*)m->logits, m->ld_logits, R, m->V, d,
                                      3, stream));   // nontemporal stores: the logits leave the caches before they are read
+        else if (c.bf16 && m->part != nullptr && tst_vocab_stats_ok(R, m->V, d))
+            // the selection pass of a beam search reads these statistics instead of the rows (tst_select_step_run)
+            TST_TRY(tst_vocabproj_stats_bf16(m->h, d, m->wout, m->ld_wout, m->bout, m->logits, m->ld_logits, R, m->V, d, m->part,
+                                             m->n_slices, stream));
         else
             TST_TRY(c.gemm(m->h, d, m->wout, m->ld_wout, m->bout, nullptr, 0, m->logits, m->ld_logits, m->V, d, 0, true));
     }
@@ -197,9 +201,13 @@ extern "C" int tst_select_step_run(const tst_select_step* s, const tst_rows* cur
                                                  n_sent, step, s->T, s->eos, last_step, s->out_tok, s->out_len, s->out_score,
                                                  s->scratch_alive_pos, s->row_parent, s->n_alive, s->n_sent_dev, stream);
     } else {
-        TST_TRY(s->bf16_logits ? tst_logsoftmax_topk_bf16(s->logits, s->ld_logits, R, s->V, s->k, s->top_val, s->top_idx, s->lse, stream)
-                               : tst_logsoftmax_topk_f32((const float*)s->logits, s->ld_logits, R, s->V, s->k, s->top_val, s->top_idx,
-                                                         s->lse, stream));
+        if (s->bf16_logits && s->part != nullptr && tst_vocab_stats_ok(R, s->V, s->stats_k))
+            TST_TRY(tst_topk_from_stats_bf16(s->logits, s->ld_logits, s->part, s->n_slices, R, s->V, s->k, s->top_val, s->top_idx, s->lse,
+                                             stream));
+        else
+            TST_TRY(s->bf16_logits ? tst_logsoftmax_topk_bf16(s->logits, s->ld_logits, R, s->V, s->k, s->top_val, s->top_idx, s->lse, stream)
+                                   : tst_logsoftmax_topk_f32((const float*)s->logits, s->ld_logits, R, s->V, s->k, s->top_val, s->top_idx,
+                                                             s->lse, stream));
         TST_TRY(tst_beam_merge(cur, s->top_val, s->top_idx, s->lse, n_sent, s->k, k_in, s->eos, s->sel_parent, s->sel_tok, s->sel_score,
                                s->sel_fin, s->sel_nemit, stream));
     }

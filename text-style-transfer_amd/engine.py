@@ -178,7 +178,7 @@ class DecodeLoop:
                                              top_idx=self.top_idx, lse=self.lse, sel=self.sel, lp=self.lp, T=Ttot,
                                              top_ends=self.top_ends, sample=self.sample, out_tok=self.out_tok, out_len=self.out_len,
                                              out_score=self.out_score, scratch=self.scratch, row_parent=self.row_parent,
-                                             n_alive=self.n_alive)
+                                             n_alive=self.n_alive, stats=getattr(s, 'stats', None))
                 elif logits.data_ptr() != self.tail.logits_ptr:
                     _check_logits(logits, R, s.V)
                     self.tail.set_logits(logits)
@@ -236,7 +236,7 @@ class DecodeLoop:
                                          top_idx=self.top_idx, lse=self.lse, sel=self.sel, lp=self.lp, T=Ttot,
                                          top_ends=self.top_ends, sample=self.sample, out_tok=self.out_tok, out_len=self.out_len,
                                          out_score=self.out_score, scratch=self.scratch, row_parent=self.row_parent,
-                                         n_alive=self.n_alive)
+                                         n_alive=self.n_alive, stats=getattr(s, 'stats', None))
             elif logits.data_ptr() != self.tail.logits_ptr:
                 _check_logits(logits, R, s.V)
                 self.tail.set_logits(logits)

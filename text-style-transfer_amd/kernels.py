@@ -274,6 +274,35 @@ def sample_rows(logits, n_rows, n_cols, temperature, seed, step, sent, out_tok):
          int(step), _p(sent), _p(out_tok), _stream())
 
 
+def vocab_stats_ok(n_rows, n_cols, k_inner):
+    return bool(_lib._dll.tst_vocab_stats_ok(n_rows, n_cols, k_inner))
+
+
+def vocabproj_stats(a, w, bias, out, part, n_rows, n_cols=None):
+    """out[:n_rows, :N] = a[:n_rows] @ w[:N].T + bias (all bf16 but the fp32 bias) and ``part`` [ceil(rows / 32), ceil(N / 64), 64]
+    fp32: per row and slice of 64 columns the largest stored logit and the sum of exp(logit - largest)."""
+    for t, nm, dt in ((a, 'a', torch.bfloat16), (w, 'w', torch.bfloat16), (out, 'out', torch.bfloat16), (bias, 'bias', torch.float32)):
+        if not (t.is_cuda and t.dtype == dt and t.stride(-1) == 1):
+            raise ValueError('%s must be a %s GPU tensor with unit inner stride' % (nm, dt))
+    _chk(part, torch.float32, 'part')
+    Kd = a.shape[1]
+    N = w.shape[0] if n_cols is None else n_cols
+    ns = (N + 63) // 64
+    assert w.shape[1] == Kd and out.shape[1] >= N and a.shape[0] >= n_rows and out.shape[0] >= n_rows
+    assert part.numel() >= (n_rows + 31) // 32 * ns * 64
+    call('tst_vocabproj_stats_bf16', _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), n_rows, N, Kd, _p(part), ns,
+         _stream())
+
+
+def topk_from_stats(logits, part, n_rows, n_cols, k, top_val, top_idx, lse):
+    _chk(top_val, torch.float32, 'top_val'); _chk(top_idx, torch.int32, 'top_idx'); _chk(lse, torch.float32, 'lse')
+    _chk(part, torch.float32, 'part')
+    if _logits_suffix(logits) != '_bf16':
+        raise ValueError('statistics exist for bf16 logits only')
+    call('tst_topk_from_stats_bf16', _p(logits), logits.stride(0), _p(part), (n_cols + 63) // 64, n_rows, n_cols, k, _p(top_val), _p(top_idx),
+         _p(lse), _stream())
+
+
 def logsoftmax_topk(logits, n_rows, n_cols, k, top_val, top_idx, lse):
     _chk(top_val, torch.float32, 'top_val'); _chk(top_idx, torch.int32, 'top_idx'); _chk(lse, torch.float32, 'lse')
     call('tst_logsoftmax_topk' + _logits_suffix(logits), _p(logits), logits.stride(0), n_rows, n_cols, k, _p(top_val), _p(top_idx), _p(lse),
@@ -287,8 +316,8 @@ class StepPlan:
     the leading dimension); the plan keeps every tensor alive."""
 
     def __init__(self, *, d, heads, d_ff, V, bf16, n_pos, slab_rows, S, anc_ld, emb, pe, scale, z, mask, ln, wout, bout,
-                 x, h, q, a, ff, logits, layers, eps=1e-5, kvrow=None, group=1, ht=None):
-        self._keep = [kvrow, emb, pe, z, mask, ln, wout, bout, x, h, q, a, ff, logits, layers, ht]
+                 x, h, q, a, ff, logits, layers, eps=1e-5, kvrow=None, group=1, ht=None, part=None):
+        self._keep = [kvrow, emb, pe, z, mask, ln, wout, bout, x, h, q, a, ff, logits, layers, ht, part]
         n = len(layers)
         self._layers = (_lib.TstTfmLayer * n)()
         for dst, L in zip(self._layers, layers):
@@ -302,7 +331,8 @@ class StepPlan:
             n_layers=n, d=d, heads=heads, d_ff=d_ff, V=V, bf16=int(bool(bf16)), group=int(group), n_pos=n_pos, slab_rows=slab_rows, S=S, anc_ld=anc_ld,
             emb=_p(emb), pe=_p(pe), scale=float(scale), eps=float(eps), z=_p(z), mask=_p(mask), kvrow=_p(kvrow), ln_g=_p(ln[0]), ln_b=_p(ln[1]),
             wout=_p(wout), bout=_p(bout), ld_wout=wout.stride(0), x=_p(x), h=_p(h), q=_p(q), a=_p(a), ff=_p(ff), logits=_p(logits),
-            ld_logits=logits.stride(0), layers=self._layers, ht=_p(ht), ld_ht=0 if ht is None else ht.stride(0))
+            ld_logits=logits.stride(0), layers=self._layers, ht=_p(ht), ld_ht=0 if ht is None else ht.stride(0),
+            part=_p(part), n_slices=(V + 63) // 64)
 
     def run(self, rows, n_rows, t, phases):
         call('tst_tfm_step_run', self.c, _p(rows.tok), _p(rows.anc), _p(rows.sent), n_rows, t, phases, _stream())
@@ -343,8 +373,9 @@ class SelectPlan:
     """Host-side ``tst_select_step``: selection + retirement + compaction of one decode step as ONE native call."""
 
     def __init__(self, *, k, eos, V, logits, am, top_val, top_idx, lse, sel, lp, T, top_ends, sample, out_tok, out_len, out_score,
-                 scratch, row_parent, n_alive):
-        self._keep = [logits, am, top_val, top_idx, lse, sel, lp, out_tok, out_len, out_score, scratch, row_parent, n_alive]
+                 scratch, row_parent, n_alive, stats=None):
+        # stats: None, or (part, K) of a session whose vocabulary projection leaves per-slice statistics beside its bf16 logits
+        self._keep = [logits, am, top_val, top_idx, lse, sel, lp, out_tok, out_len, out_score, scratch, row_parent, n_alive, stats]
         _logits_suffix(logits)   # fp32 or bf16, unit inner stride
         sp = sel.ptrs()
         self.c = _lib.TstSelectStep(
@@ -353,13 +384,15 @@ class SelectPlan:
             sel_fin=sp[3], sel_nemit=sp[4], lp=_p(lp), T=T, top_ends=int(top_ends), sample=int(sample is not None),
             temperature=float(sample[0]) if sample is not None else 1.0, seed=(int(sample[1]) & 0xffffffff) if sample is not None else 0,
             out_tok=_p(out_tok), out_len=_p(out_len), out_score=_p(out_score), scratch_alive_pos=_p(scratch),
-            row_parent=_p(row_parent), n_alive=_p(n_alive), n_sent_dev=None)
+            row_parent=_p(row_parent), n_alive=_p(n_alive), n_sent_dev=None,
+            part=None if stats is None else _p(stats[0]), n_slices=(V + 63) // 64, stats_k=0 if stats is None else int(stats[1]))
         self.logits_ptr = _p(logits)
 
     def set_logits(self, logits):
         """A model that returns a new logits tensor every step (any foreign callable)."""
         _logits_suffix(logits)
         self._keep[0] = logits
+        self.c.part = None           # statistics belong to the buffer the plan was made for
         self.c.logits, self.c.ld_logits, self.c.bf16_logits = _p(logits), logits.stride(0), int(logits.dtype == torch.bfloat16)
         self.logits_ptr = _p(logits)
 

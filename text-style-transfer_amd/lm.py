@@ -13,11 +13,17 @@ the bf16 matrix cores, fp32 residual stream, LayerNorm statistics, softmax and s
 fixed-order fp32 kernels.
 """
 import math
+import os
 
 import torch
 
 from . import kernels as K
 from .transformer import _pad_rows4, HP, HipModule, _t, sinusoid_table
+
+
+# TST_VOCAB_STATS=1: beam search on bf16 logits takes the statistics route described in TransformerLMSession.__init__.  Off by
+# default: measured on config 4 the exponentials in the projection's epilogue cost what the shorter selection pass saves.
+VOCAB_STATS = os.environ.get('TST_VOCAB_STATS', '0') == '1'
 
 
 class TransformerLM(HipModule):
@@ -189,6 +195,12 @@ class TransformerLMSession:
         self.logits = torch.empty((R, (lm.V + 7) // 8 * 8), **lo)
         self.scale = float(torch.tensor(math.sqrt(d), dtype=torch.float32))
         self._plans = {}
+        # beam search on bf16 logits: the vocabulary projection also leaves, per row and slice of 64 columns, the largest logit
+        # and the sum of exponentials, and the selection pass reads those instead of the rows (steps of a shape the
+        # statistics kernel serves; other steps run the two plain kernels).  ``stats`` = (buffer, inner dimension) or None
+        self.stats = None
+        if VOCAB_STATS and lm.dtype == 'bf16' and k > 1 and K.vocab_stats_ok(R, lm.V, d):
+            self.stats = (torch.empty(((R + 31) // 32, (lm.V + 63) // 64, 64), **f32), d)
 
     def reorder(self, row_parent, n_rows, identity):
         pass  # the KV cache is addressed through the ancestor table; nothing moves
@@ -204,7 +216,7 @@ class TransformerLMSession:
             plan = K.StepPlan(d=lm.d, heads=lm.heads, d_ff=lm.d_ff, V=self.V, bf16=lm.dtype == 'bf16', n_pos=self.cache[0].shape[0],
                               slab_rows=self.R, S=0, anc_ld=anc_ld, emb=W['emb'], pe=W['pe'], scale=self.scale, z=self.z, mask=None,
                               ln=W['ln'], wout=W['wout'], bout=W['bout'], x=self.x, h=self.h, q=None, a=self.a, ff=self.ff,
-                              logits=self.logits, layers=layers)
+                              logits=self.logits, layers=layers, part=None if self.stats is None else self.stats[0])
             self._plans[anc_ld] = plan
         return plan
 
