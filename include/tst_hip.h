@@ -36,7 +36,7 @@ extern "C" {
  * 104 = 103 + tst_gemm_dma_f32, tst_layernorm_t_f32, tst_tfm_step.ht / ld_ht, tst_attn_cross_mfma_f32,
  * tst_select_step.n_sent_dev, tst_pack_sources, tst_scatter_rows_f32;
  * 105 = 104 + tst_vocab_stats_ok, tst_vocabproj_stats_bf16, tst_topk_from_stats_bf16, tst_tfm_step.part / n_slices,
- * tst_select_step.part / n_slices / stats_k (additions only). */
+ * tst_select_step.part / n_slices / stats_k, tst_gru_cell_fused_t_f32, tst_gru_step.ht / ld_ht (additions only). */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
@@ -179,6 +179,14 @@ int tst_gru_cell_fused_ok(int64_t E, int64_t H);
 int tst_gru_cell_fused_f32(const float* x, int64_t ldx, const float* h, int64_t ldh, const float* wih, int64_t ld_wih,
                            const float* bih, const float* whh, int64_t ld_whh, const float* bhh, float* h_out, int64_t ldo,
                            int64_t R, int64_t E, int64_t H, void* stream);
+
+/* tst_gru_cell_fused_f32 that ALSO stores the new state k-major, h_out_t[j][r] = h_out[r][j] (ldt >= R floats per hidden unit):
+ * the A operand layout of tst_gemm_dma_f32, so that the output projection H -> V of a large batch stages both operands by
+ * LDS-DMA.  Same values as tst_gru_cell_fused_f32, bit for bit (the products are computed transposed: the same fma chain
+ * per element).  Additionally ldo % 4 == 0, h_out, bih, bhh 16-byte aligned, h_out_t must not overlap h. */
+int tst_gru_cell_fused_t_f32(const float* x, int64_t ldx, const float* h, int64_t ldh, const float* wih, int64_t ld_wih,
+                             const float* bih, const float* whh, int64_t ld_whh, const float* bhh, float* h_out, int64_t ldo,
+                             float* h_out_t, int64_t ldt, int64_t R, int64_t E, int64_t H, void* stream);
 
 /* dst[r][:] = src[idx[r]][:], rows of `width` floats (width % 4 == 0); carried GRU state on reorder. */
 int tst_gather_rows_f32(const float* src, const int32_t* idx, float* dst, int64_t R, int64_t width, void* stream);
@@ -413,6 +421,10 @@ typedef struct tst_gru_step {
     float *x, *gi, *gh;     /* [rows][E], [rows][3H], [rows][3H] */
     float* logits;  int64_t ld_logits;
     const tst_gru_layer* layers;   /* host array of n_layers */
+    float* ht;              /* optional: [H][ld_ht] k-major copy of the top layer's new state.  When set, a step with
+                               TST_STEP_FUSED_CELL of at least TST_DMA_MIN_ROWS rows and V >= 2048 writes it
+                               (tst_gru_cell_fused_t_f32) and its output projection is tst_gemm_dma_f32.  Same logits. */
+    int64_t ld_ht;          /* a multiple of 4, >= rows rounded up to a multiple of 128 */
 } tst_gru_step;
 
 /* phases as for tst_tfm_step_run (TST_STEP_EMBED | TST_STEP_LAYERS | TST_STEP_VOCAB). */

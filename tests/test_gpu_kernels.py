@@ -318,13 +318,21 @@ def test_gru_cell_fused_equals_three_call_form_and_oracle(K, R, E, H):
     outs = torch.zeros((R, H + 12), device='cuda')
     K.gru_cell_fused(xs[:, :E], hs[:, :H], wi, None, wh, None, outs[:, :H], R)
     assert np.array_equal(outs[:, :H].cpu().numpy(), C.gru_cell(C.gemm(x, wih), C.gemm(h, whh), h)) and (outs[:, H:] == 0).all()
+    # the form that also writes the new state k-major (the operand layout of the LDS-DMA output projection): same bits
+    out2 = torch.full((R + 2, H), 7.0, device='cuda')
+    ld = (R + 127) // 128 * 128
+    out_t = torch.full((H, ld), 7.0, device='cuda')
+    K.gru_cell_fused_t(xd, hd, wi, bi, wh, bh, out2, out_t, R)
+    assert torch.equal(out2, out) and torch.equal(out_t[:, :R], out[:R].t()) and (out_t[:, R:] == 7.0).all()
+    K.gru_cell_fused_t(xs[:, :E], hs[:, :H], wi, None, wh, None, out2, out_t, R)
+    assert torch.equal(out2[:R], outs[:, :H]) and torch.equal(out_t[:, :R], outs[:, :H].t())
     from tst_amd import _lib
     with pytest.raises(_lib.TstError, match='must not overlap'):
         K.gru_cell_fused(xd, hd, wi, bi, wh, bh, hd, R)
     assert not K.gru_cell_fused_ok(1024, 1000) and not K.gru_cell_fused_ok(1028, 1024) and K.gru_cell_fused_ok(1024, 1024)
 
 
-@pytest.mark.parametrize('M,N,Kd', [(300, 700, 64), (2049, 1000, 256), (128, 256, 16), (5, 32000, 256), (1000, 515, 512)])
+@pytest.mark.parametrize('M,N,Kd', [(300, 700, 64), (2049, 1000, 256), (128, 256, 16), (5, 32000, 256), (1000, 515, 512), (260, 520, 1024)])
 @pytest.mark.parametrize('variant', [0, 2, 3])
 def test_gemm_dma_k_major_activations_bit_exact(K, M, N, Kd, variant):
     """Both operands staged by LDS-DMA (activations given k-major): the same fma chain per element as the register-staged

@@ -59,7 +59,7 @@ class TstGruStep(ctypes.Structure):
     _fields_ = [('n_layers', c_i32), ('E', c_i32), ('H', c_i32), ('V', c_i32), ('rows', c_i64),
                 ('emb', c_vp), ('extra', c_vp), ('wout', c_vp), ('bout', c_vp), ('ld_wout', c_i64),
                 ('x', c_vp), ('gi', c_vp), ('gh', c_vp), ('logits', c_vp), ('ld_logits', c_i64),
-                ('layers', ctypes.POINTER(TstGruLayer))]
+                ('layers', ctypes.POINTER(TstGruLayer)), ('ht', c_vp), ('ld_ht', c_i64)]
 
 
 class TstSelectStep(ctypes.Structure):
@@ -94,6 +94,8 @@ _PROTOS = {
     'tst_gru_cell_step_f32': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_gru_cell_fused_ok': ([c_i64, c_i64], c_int),
     'tst_gru_cell_fused_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp], c_int),
+    'tst_gru_cell_fused_t_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64,
+                                  c_vp], c_int),
     'tst_gather_rows_f32': ([c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_scatter_rows_f32': ([c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_pack_sources': ([c_vp, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp], c_int),

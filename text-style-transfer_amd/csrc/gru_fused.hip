@@ -22,6 +22,7 @@ struct GruSmem {
 
 // acc[i][g] += A[rows of the tile][0..K) * W[0..K)[g * H + columns of the tile], g = 0..2; K % 16 == 0.
 // Called once with (x, Wih) and once with (h, Whh); the caller separates the calls with a barrier.
+template <bool OUT_T>
 __device__ __forceinline__ void gate_products(const float* __restrict__ A, int64_t lda, const float* __restrict__ W, int64_t ldw,
                                               int K, int H, int M, int m0, int n0, f32x16 (&acc)[2][3], GruSmem& sm) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6, wm = wave >> 1, wn = wave & 1;
@@ -74,7 +75,9 @@ __device__ __forceinline__ void gate_products(const float* __restrict__ A, int64
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int g = 0; g < 3; ++g) acc[i][g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[g], acc[i][g], 0, 0, 0);
+                for (int g = 0; g < 3; ++g)
+                    acc[i][g] = OUT_T ? __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur[g], a_cur[i], acc[i][g], 0, 0, 0)
+                                      : __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[i], b_cur[g], acc[i][g], 0, 0, 0);
             a_cur[0] = a_nxt[0]; a_cur[1] = a_nxt[1];
             b_cur[0] = b_nxt[0]; b_cur[1] = b_nxt[1]; b_cur[2] = b_nxt[2];
             if (kk == BK / 2 - 2) {
@@ -89,11 +92,16 @@ __device__ __forceinline__ void gate_products(const float* __restrict__ A, int64
     }
 }
 
+// OUT_T: the products are computed transposed (operands swapped: the same fma chain per element), so that a lane owns a ROW
+// of the tile and its 16 registers are 16 columns (4 groups of 4 consecutive ones): the new state goes out as 16-byte pieces
+// of rows AND a second time k-major, HoutT[column][row] (32 lanes = 128 contiguous bytes), the operand layout of the LDS-DMA
+// GEMM that multiplies it with the output projection.
+template <bool OUT_T>
 __global__ __launch_bounds__(256, 2) void gru_fused_kernel(const float* __restrict__ X, int64_t ldx, int E, const float* __restrict__ Hin,
                                                            int64_t ldh, int H, const float* __restrict__ Wih, int64_t ldwi,
                                                            const float* __restrict__ bih, const float* __restrict__ Whh, int64_t ldwh,
-                                                           const float* __restrict__ bhh, float* __restrict__ Hout, int64_t ldo, int M,
-                                                           int tiles_m, int tiles_n) {
+                                                           const float* __restrict__ bhh, float* __restrict__ Hout, int64_t ldo,
+                                                           float* __restrict__ HoutT, int64_t ldt, int M, int tiles_m, int tiles_n) {
     __shared__ __attribute__((aligned(16))) GruSmem sm;
     // workgroup id -> tile: every XCD walks a contiguous, m-grouped range of tiles (as gemm_f32_kernel)
     const int nwg = tiles_m * tiles_n;
@@ -108,8 +116,52 @@ __global__ __launch_bounds__(256, 2) void gru_fused_kernel(const float* __restri
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave >> 1, wn = wave & 1;
-    const int col = n0 + wn * 32 + (lane & 31);
     f32x16 gi[2][3], gh[2][3];
+    if (OUT_T) {
+        // lane owns row (lane & 31) of each 32-row tile; register r is column cbase + (r & 3) + 8 (r >> 2)
+        const int cbase = n0 + wn * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const float4 bi = bih != nullptr ? *reinterpret_cast<const float4*>(bih + g * H + cbase + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 bh = bhh != nullptr ? *reinterpret_cast<const float4*>(bhh + g * H + cbase + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    gi[i][g][4 * q] = bi.x; gi[i][g][4 * q + 1] = bi.y; gi[i][g][4 * q + 2] = bi.z; gi[i][g][4 * q + 3] = bi.w;
+                    gh[i][g][4 * q] = bh.x; gh[i][g][4 * q + 1] = bh.y; gh[i][g][4 * q + 2] = bh.z; gh[i][g][4 * q + 3] = bh.w;
+                }
+            }
+        gate_products<true>(X, ldx, Wih, ldwi, E, H, M, m0, n0, gi, sm);
+        __syncthreads();
+        gate_products<true>(Hin, ldh, Whh, ldwh, H, H, M, m0, n0, gh, sm);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int row = m0 + wm * 64 + i * 32 + (lane & 31);
+            const float* hp = Hin + (int64_t)min(row, M - 1) * ldh + cbase;
+            float4 hv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hv[q] = *reinterpret_cast<const float4*>(hp + 8 * q);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float4 o;
+                o.x = gru_elem(gi[i][0][4 * q], gi[i][1][4 * q], gi[i][2][4 * q], gh[i][0][4 * q], gh[i][1][4 * q], gh[i][2][4 * q], hv[q].x);
+                o.y = gru_elem(gi[i][0][4 * q + 1], gi[i][1][4 * q + 1], gi[i][2][4 * q + 1], gh[i][0][4 * q + 1], gh[i][1][4 * q + 1],
+                               gh[i][2][4 * q + 1], hv[q].y);
+                o.z = gru_elem(gi[i][0][4 * q + 2], gi[i][1][4 * q + 2], gi[i][2][4 * q + 2], gh[i][0][4 * q + 2], gh[i][1][4 * q + 2],
+                               gh[i][2][4 * q + 2], hv[q].z);
+                o.w = gru_elem(gi[i][0][4 * q + 3], gi[i][1][4 * q + 3], gi[i][2][4 * q + 3], gh[i][0][4 * q + 3], gh[i][1][4 * q + 3],
+                               gh[i][2][4 * q + 3], hv[q].w);
+                if (row < M) {
+                    *reinterpret_cast<float4*>(Hout + (int64_t)row * ldo + cbase + 8 * q) = o;
+                    float* tp = HoutT + (int64_t)(cbase + 8 * q) * ldt + row;
+                    tp[0] = o.x; tp[ldt] = o.y; tp[2 * ldt] = o.z; tp[3 * ldt] = o.w;
+                }
+            }
+        }
+        return;
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
         const float bi = bih != nullptr ? bih[g * H + col] : 0.0f;
@@ -119,9 +171,9 @@ __global__ __launch_bounds__(256, 2) void gru_fused_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) { gi[i][g][r] = bi; gh[i][g][r] = bh; }
     }
-    gate_products(X, ldx, Wih, ldwi, E, H, M, m0, n0, gi, sm);
+    gate_products<false>(X, ldx, Wih, ldwi, E, H, M, m0, n0, gi, sm);
     __syncthreads();      // every wave has read its last operands before the images are overwritten
-    gate_products(Hin, ldh, Whh, ldwh, H, H, M, m0, n0, gh, sm);
+    gate_products<false>(Hin, ldh, Whh, ldwh, H, H, M, m0, n0, gh, sm);
 
     // lane owns column col of rows row0 + (r & 3) + 8 * (r >> 2) of each 32-row tile
 #pragma unroll
@@ -146,26 +198,56 @@ __global__ __launch_bounds__(256, 2) void gru_fused_kernel(const float* __restri
 
 extern "C" int tst_gru_cell_fused_ok(int64_t E, int64_t H) { return (E >= BK && E % BK == 0 && H >= BN && H % BN == 0) ? 1 : 0; }
 
-extern "C" int tst_gru_cell_fused_f32(const float* x, int64_t ldx, const float* h, int64_t ldh, const float* wih, int64_t ld_wih,
-                                      const float* bih, const float* whh, int64_t ld_whh, const float* bhh, float* h_out,
-                                      int64_t ldo, int64_t R, int64_t E, int64_t H, void* stream) {
-    TST_REQUIRE(x && h && wih && whh && h_out, TST_ERR_ARG, "tst_gru_cell_fused_f32: null pointer");
-    TST_REQUIRE(R >= 0 && R < (1ll << 31) && E > 0 && H > 0, TST_ERR_ARG, "tst_gru_cell_fused_f32: bad sizes");
+namespace {
+
+int gru_cell_fused_impl(const char* who, const float* x, int64_t ldx, const float* h, int64_t ldh, const float* wih, int64_t ld_wih,
+                        const float* bih, const float* whh, int64_t ld_whh, const float* bhh, float* h_out, int64_t ldo, float* h_out_t,
+                        int64_t ldt, int64_t R, int64_t E, int64_t H, void* stream) {
+    TST_REQUIRE(x && h && wih && whh && h_out, TST_ERR_ARG, "%s: null pointer", who);
+    TST_REQUIRE(R >= 0 && R < (1ll << 31) && E > 0 && H > 0, TST_ERR_ARG, "%s: bad sizes", who);
     TST_REQUIRE(tst_gru_cell_fused_ok(E, H), TST_ERR_UNSUPPORTED,
-                "tst_gru_cell_fused_f32: needs E %% 16 == 0 and H %% 64 == 0 (got E=%lld, H=%lld); use the two products and tst_gru_cell_step_f32",
+                "%s: needs E %% 16 == 0 and H %% 64 == 0 (got E=%lld, H=%lld); use the two products and tst_gru_cell_step_f32", who,
                 (long long)E, (long long)H);
     TST_REQUIRE(ldx >= E && ldh >= H && ldo >= H && ld_wih >= 3 * H && ld_whh >= 3 * H && ldx % 4 == 0 && ldh % 4 == 0 && ld_wih % 4 == 0 &&
-                    ld_whh % 4 == 0, TST_ERR_ARG, "tst_gru_cell_fused_f32: leading dimensions (multiples of 4, at least the row length)");
+                    ld_whh % 4 == 0, TST_ERR_ARG, "%s: leading dimensions (multiples of 4, at least the row length)", who);
     TST_REQUIRE(tst_aligned16(x) && tst_aligned16(h) && tst_aligned16(wih) && tst_aligned16(whh), TST_ERR_ARG,
-                "tst_gru_cell_fused_f32: x, h, wih, whh must be 16-byte aligned");
+                "%s: x, h, wih, whh must be 16-byte aligned", who);
     // every workgroup reads whole rows of h while others write h_out: the two must not overlap
     const char *hb = (const char*)h, *ob = (const char*)h_out;
     const int64_t hbytes = (R > 0 ? ((R - 1) * ldh + H) : 0) * 4, obytes = (R > 0 ? ((R - 1) * ldo + H) : 0) * 4;
-    TST_REQUIRE(ob + obytes <= hb || hb + hbytes <= ob, TST_ERR_ARG, "tst_gru_cell_fused_f32: h_out must not overlap h");
+    TST_REQUIRE(ob + obytes <= hb || hb + hbytes <= ob, TST_ERR_ARG, "%s: h_out must not overlap h", who);
+    if (h_out_t != nullptr) {
+        TST_REQUIRE(ldt >= R && ldo % 4 == 0 && tst_aligned16(h_out) && tst_aligned16(bih) && tst_aligned16(bhh), TST_ERR_ARG,
+                    "%s: the k-major copy needs ldt >= R, ldo %% 4 == 0 and 16-byte aligned h_out, bih, bhh", who);
+        const char* tb = (const char*)h_out_t;
+        const int64_t tbytes = (R > 0 ? ((H - 1) * ldt + R) : 0) * 4;
+        TST_REQUIRE(tb + tbytes <= hb || hb + hbytes <= tb, TST_ERR_ARG, "%s: h_out_t must not overlap h", who);
+    }
     if (R == 0) return TST_OK;
     const int64_t tiles_m = (R + BM - 1) / BM, tiles_n = H / BN;
-    TST_REQUIRE(tiles_m * tiles_n < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gru_cell_fused_f32: grid too large");
-    hipLaunchKernelGGL(gru_fused_kernel, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)E, h, ldh,
-                       (int)H, wih, ld_wih, bih, whh, ld_whh, bhh, h_out, ldo, (int)R, (int)tiles_m, (int)tiles_n);
-    return tst_after_launch("tst_gru_cell_fused_f32");
+    TST_REQUIRE(tiles_m * tiles_n < (1ll << 31), TST_ERR_UNSUPPORTED, "%s: grid too large", who);
+    if (h_out_t != nullptr)
+        hipLaunchKernelGGL(gru_fused_kernel<true>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)E, h,
+                           ldh, (int)H, wih, ld_wih, bih, whh, ld_whh, bhh, h_out, ldo, h_out_t, ldt, (int)R, (int)tiles_m, (int)tiles_n);
+    else
+        hipLaunchKernelGGL(gru_fused_kernel<false>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)E, h,
+                           ldh, (int)H, wih, ld_wih, bih, whh, ld_whh, bhh, h_out, ldo, nullptr, 0, (int)R, (int)tiles_m, (int)tiles_n);
+    return tst_after_launch(who);
+}
+
+}  // namespace
+
+extern "C" int tst_gru_cell_fused_f32(const float* x, int64_t ldx, const float* h, int64_t ldh, const float* wih, int64_t ld_wih,
+                                      const float* bih, const float* whh, int64_t ld_whh, const float* bhh, float* h_out,
+                                      int64_t ldo, int64_t R, int64_t E, int64_t H, void* stream) {
+    return gru_cell_fused_impl("tst_gru_cell_fused_f32", x, ldx, h, ldh, wih, ld_wih, bih, whh, ld_whh, bhh, h_out, ldo, nullptr, 0, R, E, H,
+                               stream);
+}
+
+extern "C" int tst_gru_cell_fused_t_f32(const float* x, int64_t ldx, const float* h, int64_t ldh, const float* wih, int64_t ld_wih,
+                                        const float* bih, const float* whh, int64_t ld_whh, const float* bhh, float* h_out,
+                                        int64_t ldo, float* h_out_t, int64_t ldt, int64_t R, int64_t E, int64_t H, void* stream) {
+    TST_REQUIRE(h_out_t != nullptr, TST_ERR_ARG, "tst_gru_cell_fused_t_f32: null h_out_t");
+    return gru_cell_fused_impl("tst_gru_cell_fused_t_f32", x, ldx, h, ldh, wih, ld_wih, bih, whh, ld_whh, bhh, h_out, ldo, h_out_t, ldt, R,
+                               E, H, stream);
 }

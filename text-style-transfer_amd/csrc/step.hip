@@ -137,6 +137,12 @@ extern "C" int tst_gru_step_run(const tst_gru_step* m, const int32_t* tok, const
     }
     const tst_gru_layer& top = m->layers[m->n_layers - 1];
     const float* top_h = top.h;   // the state the output projection reads
+    // large fused steps with a wide vocabulary: the top cell also writes its state k-major and the projection stages both
+    // operands by LDS-DMA
+    const bool dma_vocab = fused && m->ht != nullptr && (phases & TST_STEP_LAYERS) && (phases & TST_STEP_VOCAB) && R >= TST_DMA_MIN_ROWS &&
+                           m->V >= 2048 && m->H % 16 == 0;
+    TST_REQUIRE(!dma_vocab || (m->ld_ht % 4 == 0 && m->ld_ht >= (R + 127) / 128 * 128), TST_ERR_ARG,
+                "tst_gru_step_run: ld_ht must be a multiple of 4 and at least the rows rounded up to 128");
     if (phases & TST_STEP_LAYERS) {
         if (m->extra != nullptr) {
             TST_REQUIRE(sent != nullptr, TST_ERR_ARG, "tst_gru_step_run: extra without sent");
@@ -149,8 +155,12 @@ extern "C" int tst_gru_step_run(const tst_gru_step* m, const int32_t* tok, const
             TST_REQUIRE(L.wih && L.whh && L.h, TST_ERR_ARG, "tst_gru_step_run: layer %d incomplete", l);
             if (fused) {
                 TST_REQUIRE(L.h_alt != nullptr, TST_ERR_ARG, "tst_gru_step_run: layer %d has no h_alt", l);
-                TST_TRY(tst_gru_cell_fused_f32(x, in, L.h, m->H, L.wih, L.ld_wih, L.bih, L.whh, L.ld_whh, L.bhh, L.h_alt, m->H, R, in,
-                                               m->H, stream));
+                if (dma_vocab && l == m->n_layers - 1)
+                    TST_TRY(tst_gru_cell_fused_t_f32(x, in, L.h, m->H, L.wih, L.ld_wih, L.bih, L.whh, L.ld_whh, L.bhh, L.h_alt, m->H, m->ht,
+                                                     m->ld_ht, R, in, m->H, stream));
+                else
+                    TST_TRY(tst_gru_cell_fused_f32(x, in, L.h, m->H, L.wih, L.ld_wih, L.bih, L.whh, L.ld_whh, L.bhh, L.h_alt, m->H, R, in,
+                                                   m->H, stream));
                 x = L.h_alt;
                 in = m->H;
                 continue;
@@ -165,8 +175,11 @@ extern "C" int tst_gru_step_run(const tst_gru_step* m, const int32_t* tok, const
     if (fused && (phases & TST_STEP_LAYERS)) top_h = top.h_alt;
     if (phases & TST_STEP_VOCAB) {
         TST_REQUIRE(m->wout != nullptr, TST_ERR_ARG, "tst_gru_step_run: null output projection");
-        TST_TRY(tst_gemm_mfma_f32(top_h, m->H, m->wout, m->ld_wout, m->bout, nullptr, 0, m->logits, m->ld_logits, R, m->V, m->H, 0,
-                                  stream));
+        if (dma_vocab)
+            TST_TRY(tst_gemm_dma_f32(m->ht, m->ld_ht, m->wout, m->ld_wout, m->bout, m->logits, m->ld_logits, R, m->V, m->H, 3, stream));
+        else
+            TST_TRY(tst_gemm_mfma_f32(top_h, m->H, m->wout, m->ld_wout, m->bout, nullptr, 0, m->logits, m->ld_logits, R, m->V, m->H, 0,
+                                      stream));
     }
     return TST_OK;
 }

@@ -224,6 +224,18 @@ def gru_cell_fused(x, h, wih, bih, whh, bhh, h_out, n_rows):
          _p(bhh), _p(h_out), h_out.stride(0), n_rows, E, H, _stream())
 
 
+def gru_cell_fused_t(x, h, wih, bih, whh, bhh, h_out, h_out_t, n_rows):
+    """``gru_cell_fused`` that also writes the new state k-major: ``h_out_t`` [H, ld >= n_rows]"""
+    for t, nm in ((x, 'x'), (h, 'h'), (wih, 'wih'), (whh, 'whh'), (h_out, 'h_out'), (bih, 'bih'), (bhh, 'bhh'), (h_out_t, 'h_out_t')):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1):
+            raise ValueError('%s must be an fp32 GPU tensor with unit inner stride' % nm)
+    E, H = wih.shape[0], whh.shape[0]
+    assert x.shape[1] == E and h.shape[1] == H and h_out.shape[1] == H and min(x.shape[0], h.shape[0], h_out.shape[0]) >= n_rows
+    assert h_out_t.shape[0] == H and h_out_t.shape[1] >= n_rows
+    call('tst_gru_cell_fused_t_f32', _p(x), x.stride(0), _p(h), h.stride(0), _p(wih), wih.stride(0), _p(bih), _p(whh), whh.stride(0),
+         _p(bhh), _p(h_out), h_out.stride(0), _p(h_out_t), h_out_t.stride(0), n_rows, E, H, _stream())
+
+
 def gather_rows(src, idx, dst, n_rows):
     _chk(src, torch.float32, 'src'); _chk(dst, torch.float32, 'dst'); _chk(idx, torch.int32, 'idx')
     assert src.shape[1] == dst.shape[1]
@@ -343,8 +355,8 @@ class GruPlan:
     ``wih, bih, whh, bhh``; ``h`` / ``h_alt`` are the session's lists of state buffers, which ``swap()`` exchanges
     after a reorder."""
 
-    def __init__(self, *, E, H, V, rows, emb, extra, cells, h, h_alt, wout, bout, x, gi, gh, logits):
-        self._keep = [emb, extra, cells, h, h_alt, wout, bout, x, gi, gh, logits]
+    def __init__(self, *, E, H, V, rows, emb, extra, cells, h, h_alt, wout, bout, x, gi, gh, logits, ht=None):
+        self._keep = [emb, extra, cells, h, h_alt, wout, bout, x, gi, gh, logits, ht]
         n = len(cells)
         self._layers = (_lib.TstGruLayer * n)()
         for dst, c, a, b in zip(self._layers, cells, h, h_alt):
@@ -353,7 +365,7 @@ class GruPlan:
             dst.h, dst.h_alt = _p(a), _p(b)
         self.c = _lib.TstGruStep(n_layers=n, E=E, H=H, V=V, rows=rows, emb=_p(emb), extra=_p(extra), wout=_p(wout), bout=_p(bout),
                                  ld_wout=wout.stride(0), x=_p(x), gi=_p(gi), gh=_p(gh), logits=_p(logits),
-                                 ld_logits=logits.stride(0), layers=self._layers)
+                                 ld_logits=logits.stride(0), layers=self._layers, ht=_p(ht), ld_ht=0 if ht is None else ht.stride(0))
 
     def run(self, rows, n_rows, phases):
         """With ``STEP_FUSED_CELL`` in ``phases`` (and the layers run) the new state of every layer lands in ``h_alt``: the

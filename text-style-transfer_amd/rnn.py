@@ -189,13 +189,19 @@ class GRUSession:
         self.gi = torch.empty((R, 3 * model.H), **f32)
         self.gh = torch.empty((R, 3 * model.H), **f32)
         self.logits = torch.empty((R, (model.V + 3) // 4 * 4), **f32)
+        # wide vocabulary, many rows: the top cell also writes its state k-major and the output projection stages both
+        # operands by LDS-DMA (tst_gru_step.ht)
+        self.ht = None
+        if R >= K.DMA_MIN_ROWS and model.V >= 2048 and model.H % 16 == 0 and K.gru_cell_fused_ok(model.E, model.H):
+            self.ht = torch.empty((model.H, (R + 127) // 128 * 128), **f32)
         self.plan = None
 
     def _plan(self):
         if self.plan is None:
             m, W = self.m, self.m.prepared()
             self.plan = K.GruPlan(E=m.E, H=m.H, V=m.V, rows=self.R, emb=W['emb'], extra=self.extra, cells=W['cells'], h=self.h,
-                                  h_alt=self.h_alt, wout=W['wout'], bout=W['bout'], x=self.x, gi=self.gi, gh=self.gh, logits=self.logits)
+                                  h_alt=self.h_alt, wout=W['wout'], bout=W['bout'], x=self.x, gi=self.gi, gh=self.gh, logits=self.logits,
+                                  ht=self.ht)
         return self.plan
 
     def reorder(self, row_parent, n_rows, identity):

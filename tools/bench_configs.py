@@ -82,6 +82,31 @@ def gru_cell_roofline(model, rows):
           flush=True)
 
 
+def gru_vocab_roofline(model, rows):
+    """The output projection H -> V of the GRU decoder at `rows` rows as the decode step runs it for large batches (state
+    k-major, both operands by LDS-DMA), HIP events over 10 launches: 2 * rows * H * V FLOP against 157.3 TFLOP/s."""
+    from tst_amd import kernels as K
+    W = model.prepared()
+    H, V = W['wout'].shape[0], model.V
+    ht = torch.randn((H, (rows + 127) // 128 * 128), device=model.device)
+    out = torch.empty((rows, (V + 3) // 4 * 4), device=model.device)
+    fn = lambda: K.gemm_dma(ht, W['wout'], W['bout'], out, rows, n_cols=V, variant=3)   # noqa: E731
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / 10 * 1e3
+    tf = 2.0 * rows * H * V / us / 1e6
+    print(json.dumps({'kernel': 'gemm_f32_dma_kernel (GRU output projection, K=%d V=%d)' % (H, V), 'rows': rows, 'avg_launch_us': round(us, 1),
+                      'roofline': {'bound': 'mfma', 'achieved': round(tf, 1), 'peak': 157.3, 'unit': 'TFLOP/s', 'frac': round(tf / 157.3, 3)}}),
+          flush=True)
+    del ht, out
+
+
 def cfg3(n_sent, bias=None):
     dev = torch.device('cuda', 0)
     for V, eos_bias in ((128, 0.5), (32000, 1.0)):
@@ -92,6 +117,8 @@ def cfg3(n_sent, bias=None):
         z = torch.randn((n_sent, 1024), generator=torch.Generator().manual_seed(1237)).to(dev)
         for beam in (1, 4):
             gru_cell_roofline(model, n_sent * beam)
+            if V >= 2048:
+                gru_vocab_roofline(model, n_sent * beam)
             run('cfg3 GRU H=1024 V=%d beam=%d fp32 max_len=100' % (V, beam),
                 lambda: tst_amd.InferenceState({'model': model, 'inputs': z, 'vocab': vocab, 'max_len': 100, 'eos_token': '|',
                                                 'beam_size': beam}), n_sent)
