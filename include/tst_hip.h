@@ -36,7 +36,8 @@ extern "C" {
  * 104 = 103 + tst_gemm_dma_f32, tst_layernorm_t_f32, tst_tfm_step.ht / ld_ht, tst_attn_cross_mfma_f32,
  * tst_select_step.n_sent_dev, tst_pack_sources, tst_scatter_rows_f32;
  * 105 = 104 + tst_vocab_stats_ok, tst_vocabproj_stats_bf16, tst_topk_from_stats_bf16, tst_tfm_step.part / n_slices,
- * tst_select_step.part / n_slices / stats_k, tst_gru_cell_fused_t_f32, tst_gru_step.ht / ld_ht (additions only). */
+ * tst_select_step.part / n_slices / stats_k, tst_gru_cell_fused_t_f32, tst_gru_step.ht / ld_ht;
+ * 106 = 105 + tst_chain_ok, tst_chain_f32 (additions only). */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
@@ -93,6 +94,23 @@ int tst_gemm_skinny_f32(const float* A, int64_t lda, const float* Wt, int64_t ld
  * receives the normalised rows.  x is [M][K] contiguous. */
 int tst_ln_gemm_f32(const float* x, const float* gamma, const float* beta, float eps, float* h, const float* Wt, int64_t ldw,
                     const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream);
+
+/* A residual product, the LayerNorm behind it and the product behind that as ONE kernel per tile of 64 whole rows
+ * (d_model = 256):
+ *     x[m][:] += A[m][:] * W1t + b1                      (tst_gemm_mfma_f32 with res == C == x; K1 inner elements)
+ *     y[m][:]  = LayerNorm(x[m][:])                      (tst_layernorm_f32)
+ *     C[m][:]  = act2(y[m][:] * W2t + b2)                (tst_gemm_mfma_f32, N2 columns; act2 = 1: relu)
+ * or, with N2 == 0, yT[k][m] = y[m][k] (tst_layernorm_t_f32: the k-major operand of tst_gemm_dma_f32) instead of the last line.
+ * Neither x nor y travels through memory between the three operations.  Results are bit-identical to the three separate
+ * calls (same fma chains, same order of the LayerNorm partial sums).  These are the chains of a pre-norm decoder layer:
+ * attention output projection -> LayerNorm -> cross-attention q projection / first feed-forward product, second feed-forward
+ * product -> LayerNorm -> next layer's q|k|v projection or the final LayerNorm, in the model called at
+ * /root/reference/src/inference.py:132.  Requirements (tst_chain_ok): d == 256, K1 a multiple of 256, N2 in {0, 256, 768,
+ * 1024}; x is [R][256] contiguous; lda, ldw1, ldw2 multiples of 4; 16-byte aligned A, W1t, W2t, b1, x, gamma, beta; ldt >= R. */
+int tst_chain_ok(int64_t R, int64_t d, int64_t K1, int64_t N2);
+int tst_chain_f32(const float* A, int64_t lda, int64_t K1, const float* W1t, int64_t ldw1, const float* b1, float* x,
+                  const float* gamma, const float* beta, float eps, const float* W2t, int64_t ldw2, const float* b2, int act2,
+                  float* C, int64_t ldc, int64_t N2, float* yT, int64_t ldt, int64_t R, int64_t d, void* stream);
 
 /* y = LayerNorm(x) as above with the result rounded to bf16 (the operand of a following bf16 GEMM). */
 int tst_layernorm_f32_bf16(const float* x, const float* gamma, const float* beta, float eps, void* y, int64_t R, int64_t d,

@@ -86,6 +86,9 @@ _PROTOS = {
     'tst_layernorm_t_f32': ([c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_gemm_skinny_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp], c_int),
     'tst_ln_gemm_f32': ([c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp], c_int),
+    'tst_chain_ok': ([c_i64, c_i64, c_i64, c_i64], c_int),
+    'tst_chain_f32': ([c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp, c_int, c_vp, c_i64, c_i64, c_vp, c_i64,
+                       c_i64, c_i64, c_vp], c_int),
     'tst_attn_self_step_f32': ([c_vp, c_i64, c_vp, c_i64, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_attn_cross_step_f32': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_attn_cross_packed_f32': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),

@@ -35,6 +35,14 @@ struct StepCtx {
     }
 };
 
+// TST_TFM_CHAIN=1 in the environment (measurements): large fp32 steps of a d_model = 256 decoder with cross-attention run the
+// residual product -> LayerNorm -> next product chains as one kernel each (tst_chain_f32).  Same results; measured slower
+// than the separate launches at most row counts (a 64-row tile per CU: rounds of 16384 rows), hence off by default.
+bool tst_tfm_chain() {
+    static const bool v = [] { const char* e = getenv("TST_TFM_CHAIN"); return e != nullptr && e[0] == '1'; }();
+    return v;
+}
+
 }  // namespace
 
 #define TST_TRY(expr)               \
@@ -72,7 +80,42 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
     }
     if (phases & TST_STEP_LAYERS) {
         TST_REQUIRE(anc != nullptr, TST_ERR_ARG, "tst_tfm_step_run: null ancestor table");
-        for (int li = 0; li < m->n_layers; ++li) {
+        bool chain = dma_vocab && tst_tfm_chain() && R >= 8192 && tst_chain_ok(R, d, d, d) && tst_chain_ok(R, d, d, m->d_ff) &&
+                     tst_chain_ok(R, d, m->d_ff, 3 * d) && tst_chain_ok(R, d, m->d_ff, 0);
+        for (int li = 0; chain && li < m->n_layers; ++li) chain = m->layers[li].cwq != nullptr;
+        for (int li = 0; chain && li < m->n_layers; ++li) {
+            const tst_tfm_layer& L = m->layers[li];
+            TST_REQUIRE(L.cache && L.wqkv && L.wo && L.w1 && L.w2 && L.kv_cross && L.cwo && m->q && sent, TST_ERR_ARG,
+                        "tst_tfm_step_run: layer %d incomplete", li);
+            float* slab = (float*)L.cache + t * m->slab_rows * 3 * d;
+            float* xf = m->x;
+            if (li == 0) TST_TRY(c.ln_gemm(L.ln_self_g, L.ln_self_b, L.wqkv, L.ld_wqkv, L.bqkv, slab, 3 * d, 3 * d, 0));
+            TST_TRY(tst_attn_self_step_f32((const float*)L.cache, m->slab_rows, anc, m->anc_ld, t, (float*)m->a, R, d, m->heads, stream));
+            TST_TRY(tst_chain_f32((const float*)m->a, d, d, (const float*)L.wo, L.ld_wo, L.bo, xf, L.ln_cross_g, L.ln_cross_b, m->eps,
+                                  (const float*)L.cwq, L.ld_cwq, L.cbq, 0, (float*)m->q, d, d, nullptr, 0, R, d, stream));
+            if (m->group > 1 && R % m->group == 0)
+                TST_TRY(tst_attn_cross_group_f32((const float*)m->q, (const float*)L.kv_cross, m->mask, sent, m->kvrow, m->S, (float*)m->a, R,
+                                                 d, m->heads, m->group, stream));
+            else if (m->kvrow != nullptr)
+                TST_TRY(tst_attn_cross_packed_f32((const float*)m->q, (const float*)L.kv_cross, m->mask, sent, m->kvrow, m->S, (float*)m->a, R,
+                                                  d, m->heads, stream));
+            else
+                TST_TRY(tst_attn_cross_step_f32((const float*)m->q, (const float*)L.kv_cross, m->mask, sent, m->S, (float*)m->a, R, d,
+                                                m->heads, stream));
+            TST_TRY(tst_chain_f32((const float*)m->a, d, d, (const float*)L.cwo, L.ld_cwo, L.cbo, xf, L.ln_ff_g, L.ln_ff_b, m->eps,
+                                  (const float*)L.w1, L.ld_w1, L.b1, 1, (float*)m->ff, m->d_ff, m->d_ff, nullptr, 0, R, d, stream));
+            if (li + 1 < m->n_layers) {
+                const tst_tfm_layer& Ln = m->layers[li + 1];
+                TST_REQUIRE(Ln.cache && Ln.wqkv, TST_ERR_ARG, "tst_tfm_step_run: layer %d incomplete", li + 1);
+                float* slab_n = (float*)Ln.cache + t * m->slab_rows * 3 * d;
+                TST_TRY(tst_chain_f32((const float*)m->ff, m->d_ff, m->d_ff, (const float*)L.w2, L.ld_w2, L.b2, xf, Ln.ln_self_g, Ln.ln_self_b,
+                                      m->eps, (const float*)Ln.wqkv, Ln.ld_wqkv, Ln.bqkv, 0, slab_n, 3 * d, 3 * d, nullptr, 0, R, d, stream));
+            } else {
+                TST_TRY(tst_chain_f32((const float*)m->ff, m->d_ff, m->d_ff, (const float*)L.w2, L.ld_w2, L.b2, xf, m->ln_g, m->ln_b, m->eps,
+                                      nullptr, 0, nullptr, 0, nullptr, 0, 0, m->ht, m->ld_ht, R, d, stream));
+            }
+        }
+        for (int li = 0; !chain && li < m->n_layers; ++li) {
             const tst_tfm_layer& L = m->layers[li];
             TST_REQUIRE(L.cache && L.wqkv && L.wo && L.w1 && L.w2, TST_ERR_ARG, "tst_tfm_step_run: layer %d incomplete", li);
             char* slab = (char*)L.cache + t * m->slab_rows * 3 * d * esz;   // the rows of position t
@@ -103,7 +146,8 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
             TST_TRY(c.ln_gemm(L.ln_ff_g, L.ln_ff_b, L.w1, L.ld_w1, L.b1, m->ff, m->d_ff, m->d_ff, 1));
             TST_TRY(c.gemm(m->ff, m->d_ff, L.w2, L.ld_w2, L.b2, m->x, d, m->x, d, d, m->d_ff, 0, false));
         }
-        if (dma_vocab) TST_TRY(tst_layernorm_t_f32(m->x, m->ln_g, m->ln_b, m->eps, m->ht, m->ld_ht, R, d, stream));
+        if (chain) {}   // the last chain wrote the final LayerNorm k-major
+        else if (dma_vocab) TST_TRY(tst_layernorm_t_f32(m->x, m->ln_g, m->ln_b, m->eps, m->ht, m->ld_ht, R, d, stream));
         else TST_TRY(c.layernorm(m->x, m->ln_g, m->ln_b, m->h));
     }
     if (phases & TST_STEP_VOCAB) {

@@ -99,6 +99,30 @@ def ln_gemm(x, gamma, beta, h, wt, bias, out, n_rows, n_cols=None, act=0, eps=1e
          n_rows, N, K, int(act), _stream())
 
 
+def chain_ok(n_rows, d, k1, n2):
+    return bool(_lib._dll.tst_chain_ok(n_rows, d, k1, n2))
+
+
+def chain(a, w1t, b1, x, gamma, beta, n_rows, w2t=None, b2=None, out=None, n_cols=None, act2=0, out_t=None, eps=1e-5):
+    """x[:n_rows] += a[:n_rows] @ w1t + b1; y = LayerNorm(x); then ``out[:n_rows, :N2] = act2(y @ w2t[:, :N2] + b2)``, or,
+    without ``w2t``, ``out_t[k, r] = y[r, k]``: one kernel per tile of 64 rows (d_model 256)."""
+    for t, nm in ((a, 'a'), (w1t, 'w1t'), (w2t, 'w2t'), (out, 'out'), (b1, 'b1'), (b2, 'b2'), (out_t, 'out_t')):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1):
+            raise ValueError('%s must be an fp32 GPU tensor with unit inner stride' % nm)
+    _chk(x, torch.float32, 'x'); _chk(gamma, torch.float32, 'gamma'); _chk(beta, torch.float32, 'beta')
+    K1, d = w1t.shape[0], x.shape[1]
+    assert a.shape[1] == K1 and w1t.shape[1] >= d and min(a.shape[0], x.shape[0]) >= n_rows and gamma.numel() == d and beta.numel() == d
+    N2 = 0
+    if w2t is not None:
+        N2 = w2t.shape[1] if n_cols is None else n_cols
+        assert w2t.shape[0] == d and out.shape[1] >= N2 and out.shape[0] >= n_rows and (b2 is None or b2.numel() >= N2)
+    else:
+        assert out_t is not None and out_t.shape[0] == d and out_t.shape[1] >= n_rows
+    call('tst_chain_f32', _p(a), a.stride(0), K1, _p(w1t), w1t.stride(0), _p(b1), _p(x), _p(gamma), _p(beta), float(eps),
+         _p(w2t), 0 if w2t is None else w2t.stride(0), _p(b2), int(act2), _p(out), 0 if out is None else out.stride(0), N2,
+         _p(out_t), 0 if out_t is None else out_t.stride(0), n_rows, d, _stream())
+
+
 def add_rows(x, z, idx, n_rows):
     """x[r] += z[idx[r]]"""
     _chk(x, torch.float32, 'x'); _chk(z, torch.float32, 'z'); _chk(idx, torch.int32, 'idx')
