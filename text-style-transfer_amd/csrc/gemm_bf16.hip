@@ -694,9 +694,9 @@ bool tst_bf16_no_persist() {
     return v;
 }
 
-// TST_BF16_TILE=0|1|2 forces the 128 x 128, 256 x 128 or 256 x 256 tile (measurements)
+// TST_BF16_TILE=0|1|2|3 forces the 128 x 128, 256 x 128, 256 x 256 or 128 x 512 (whole rows of a 512-column result) tile (measurements)
 int tst_bf16_forced_shape() {
-    static const int v = [] { const char* e = getenv("TST_BF16_TILE"); return (e != nullptr && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : -1; }();
+    static const int v = [] { const char* e = getenv("TST_BF16_TILE"); return (e != nullptr && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : -1; }();
     return v;
 }
 
@@ -731,7 +731,8 @@ extern "C" int tst_gemm_mfma_bf16(const void* A, int64_t lda, const void* W, int
                                : (big_tiles >= 192 ? 2 : mid_tiles >= 128 ? 1 : 0);
         if (const int forced = tst_bf16_forced_shape(); forced >= 0) shape = forced;
         const bool big = shape == 2;
-        const int64_t tm = shape >= 1 ? (M + 255) / 256 : (M + 127) / 128, tn = shape == 2 ? (N + 255) / 256 : (N + 127) / 128;
+        const int64_t tm = shape == 3 ? (M + 127) / 128 : shape >= 1 ? (M + 255) / 256 : (M + 127) / 128;
+        const int64_t tn = shape == 3 ? (N + 511) / 512 : shape == 2 ? (N + 255) / 256 : (N + 127) / 128;
         TST_REQUIRE(tm * tn < (1ll << 31), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_bf16: grid too large");
         const dim3 g2((unsigned)(tm * tn));
         // (N % 4: the persistent kernel fetches the bias in aligned groups of 4)
@@ -748,7 +749,10 @@ extern "C" int tst_gemm_mfma_bf16(const void* A, int64_t lda, const void* W, int
         }
 #define TST_BF16_DMA(OB, HR, RL)                                                                                      \
     do {                                                                                                              \
-        if (shape == 2)                                                                                               \
+        if (shape == 3)                                                                                               \
+            hipLaunchKernelGGL((gemm_bf16_dma_kernel<2, 4, 2, 4, 3, OB, HR, RL>), g2, dim3(512), 0, st, (const __bf16*)A, lda, \
+                               (const __bf16*)W, ldw, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, (int)tm, (int)tn); \
+        else if (shape == 2)                                                                                          \
             hipLaunchKernelGGL((gemm_bf16_dma_kernel<2, 4, 4, 2, 3, OB, HR, RL>), g2, dim3(512), 0, st, (const __bf16*)A, lda, \
                                (const __bf16*)W, ldw, bias, res, ldr, C, ldc, (int)M, (int)N, (int)K, (int)tm, (int)tn); \
         else if (shape == 1)                                                                                          \

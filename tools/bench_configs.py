@@ -7,7 +7,7 @@ this script only measures them for the design notes).  One JSON line per case.
   cfg4: z-conditioned transformer LM, model_size 512, 6 layers, 8 heads, d_ff 2048, V = 32000, beam 8, bf16
         (and the same in fp32 for comparison)
 
-Usage: python tools/bench_configs.py [cfg1|cfg3|cfg4|all] [--sentences N]
+Usage: python tools/bench_configs.py [cfg1|cfg3|cfg4|all] [--sentences N] [--streams S]
 """
 import argparse
 import json
@@ -55,6 +55,53 @@ def cfg1(n_sent, bias=None):
             return tst_amd.InferenceState({'model': model.decoder, 'inputs': encs, 'enc_mask': mask, 'vocab': vocab,
                                            'max_len': bench.MAX_LEN})
         run('cfg1 transformer-mt V=32000 greedy fp32 max_len=50 (encoder included)', make, B, repeats=5)
+
+
+def cfg1_streams(n_sent, n_streams, bias=None, repeats=8):
+    """The same small batches, `n_streams` of them at a time: every host thread decodes its own batches on a HIP stream of its
+    own (independent InferenceStates over one model; the library is safe for one thread per stream).  A batch of this size
+    is a chain of dependent small launches that leaves most of the GPU idle, so independent batches overlap almost freely:
+    the line reports the aggregate rate and the latency of a batch under that load."""
+    import threading
+    import bench
+    dev = torch.device('cuda', 0)
+    model, vocab = bench.build_model(dev, 5.5 if bias is None else bias)
+    srcs = [synthetic.multi30k_like_sources(n_sent, bench.VOCAB, seed=1235 + i).to(dev) for i in range(n_streams)]
+    streams = [torch.cuda.Stream() for _ in range(n_streams)]
+    stats = [None] * n_streams
+
+    def work(i, reps):
+        torch.cuda.set_device(dev)
+        emitted, lat = 0, []
+        with torch.cuda.stream(streams[i]):
+            for _ in range(reps):
+                t0 = time.time()
+                encs, mask = model.encoder(srcs[i])
+                st = tst_amd.InferenceState({'model': model.decoder, 'inputs': encs, 'enc_mask': mask, 'vocab': vocab,
+                                             'max_len': bench.MAX_LEN})
+                tok, lens, _ = st.decode_packed()
+                emitted += int((lens.cpu().long() - 1).clamp(min=0).sum())
+                lat.append(time.time() - t0)
+        stats[i] = (emitted, lat)
+
+    def round_(reps):
+        ths = [threading.Thread(target=work, args=(i, reps)) for i in range(n_streams)]
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        torch.cuda.synchronize()
+
+    round_(1)                               # warm-up
+    t0 = time.time()
+    round_(repeats)
+    dt = time.time() - t0
+    emitted = sum(s_[0] for s_ in stats)
+    lat = sorted(x for s_ in stats for x in s_[1])
+    print(json.dumps({'case': 'cfg1 transformer-mt V=32000 greedy fp32 max_len=50 (encoder included), concurrent batches',
+                      'sentences_per_batch': n_sent, 'streams': n_streams, 'batches': n_streams * repeats,
+                      'tokens_per_s': emitted / dt, 'ms_per_batch_amortised': dt * 1e3 / (n_streams * repeats),
+                      'batch_latency_ms_median': lat[len(lat) // 2] * 1e3, 'batch_latency_ms_max': lat[-1] * 1e3}), flush=True)
 
 
 def gru_cell_roofline(model, rows):
@@ -146,8 +193,11 @@ if __name__ == '__main__':
     ap.add_argument('--sentences', type=int, default=8192)
     ap.add_argument('--dtype', default=None, help='cfg4: only this dtype (bf16 or fp32)')
     ap.add_argument('--eos-bias', type=float, default=None, help='override the calibrated EOS bias (calibration runs)')
+    ap.add_argument('--streams', type=int, default=0, help='cfg1: that many batches at a time, one host thread and HIP stream each')
     a = ap.parse_args()
-    if a.which == 'cfg1':
+    if a.which == 'cfg1' and a.streams > 0:
+        cfg1_streams(a.sentences, a.streams, a.eos_bias)
+    elif a.which == 'cfg1':
         cfg1(a.sentences, a.eos_bias)
     if a.which in ('cfg3', 'all'):
         cfg3(a.sentences, a.eos_bias)

@@ -23,19 +23,12 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-// every thread keeps four 16-byte loads in flight per trip
+// one 16-byte element per thread, nontemporal load and store, a grid of n / 256 workgroups: the fastest of the shapes tried
+// (tools/probe/copy_variants.hip: 6.45 TB/s; workgroups that copy 16-32 KiB pieces 5.4-5.8, grid-stride loops 4.5-4.9,
+// hipMemcpyAsync 4.9)
 __global__ __launch_bounds__(256) void copy_kernel(const f32x4* __restrict__ src, f32x4* __restrict__ dst, int64_t n) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n; i += 4 * stride) {
-        const f32x4 a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride),
-                     c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
-        __builtin_nontemporal_store(a, dst + i);
-        __builtin_nontemporal_store(b, dst + i + stride);
-        __builtin_nontemporal_store(c, dst + i + 2 * stride);
-        __builtin_nontemporal_store(d, dst + i + 3 * stride);
-    }
-    for (; i < n; i += stride) dst[i] = src[i];
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) __builtin_nontemporal_store(__builtin_nontemporal_load(src + i), dst + i);
 }
 
 // read-only pass (sum of every element): what a kernel that only reads, like the selection pass over the logits, can reach
@@ -145,7 +138,7 @@ int main() {
     CHECK(hipMalloc(&dst, bytes));
     CHECK(hipMemset(src, 1, bytes));
     const int64_t n = bytes / 16;
-    const float copy_ms = time_ms([&] { hipLaunchKernelGGL(copy_kernel, dim3(cus * 16), dim3(256), 0, 0, (const f32x4*)src, (f32x4*)dst, n); }, 10);
+    const float copy_ms = time_ms([&] { hipLaunchKernelGGL(copy_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, (const f32x4*)src, (f32x4*)dst, n); }, 10);
     const double copy_gbs = 2.0 * bytes / (copy_ms * 1e-3) / 1e9;
     const float read_ms = time_ms([&] { hipLaunchKernelGGL(read_kernel, dim3(cus * 16), dim3(256), 0, 0, src, (float*)dst, n); }, 10);
     const int64_t rows = bytes / (8192 * 16);
@@ -168,7 +161,7 @@ int main() {
 
     printf("{\"device\": \"%s\", \"compute_units\": %d, \"copy_GBps\": %.1f, \"read_GBps\": %.1f, \"copy_bytes_each_way\": %lld, "
            "\"mfma_f32_TFLOPs\": %.1f, \"mfma_bf16_TFLOPs\": %.1f, "
-           "\"method\": \"float4 copy kernel (read + written bytes, nontemporal, 4 loads in flight per thread) and read-only sum kernels (grid-stride, and one workgroup per contiguous 128 KB row with 8 loads in flight: the better of the two); v_mfma_f32_32x32x2_f32 and v_mfma_f32_32x32x16_bf16 loops, "
+           "\"method\": \"float4 copy kernel (read + written bytes, nontemporal, one element per thread) and read-only sum kernels (grid-stride, and one workgroup per contiguous 128 KB row with 8 loads in flight: the better of the two); v_mfma_f32_32x32x2_f32 and v_mfma_f32_32x32x16_bf16 loops, "
            "register operands (pseudo-random), 4 accumulators per wave, 2 waves per SIMD\"}\n",
            prop.name, cus, copy_gbs, read_gbs, (long long)bytes, f32_tf, bf16_tf);
     return 0;
