@@ -175,3 +175,37 @@ def test_loop_without_per_step_count_read_equals_exact_loop(T, beam):
         assert res[0] == res[1]
     finally:
         engine.LAG_MAX_ROWS = old
+
+
+@pytest.mark.parametrize('beam', [1, 4])
+def test_concurrent_batches_on_streams_of_their_own_equal_sequential_decodes(T, beam):
+    """Independent batches decoded at the same time, one host thread and one HIP stream each over ONE model object, give the
+    outputs of the same batches decoded one after the other (the library keeps no state between calls and launches on the
+    stream it is given)."""
+    import threading
+    tmodel, model, vocab, _, _ = mt_case(T, 200, 4, 9, 2.0, 5)
+    cases = []
+    for i in range(4):
+        r = np.random.RandomState(100 + i)
+        B, S = 40 + 13 * i, 9
+        lens = r.randint(1, S + 1, size=B)
+        cases.append((r.standard_normal((B, S, 256)).astype(np.float32), (np.arange(S)[None] < lens[:, None])[:, None, :]))
+    want = [decode(T, model, vocab, e, m, 20, beam)[0] for e, m in cases]
+    got, errors = [None] * len(cases), []
+
+    def work(i):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for _ in range(3):                 # several rounds, so that the threads really overlap
+                    got[i] = decode(T, model, vocab, cases[i][0], cases[i][1], 20, beam)[0]
+        except Exception as e:                     # noqa: BLE001 - reported below, in the test's thread
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(len(cases))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    assert got == want
