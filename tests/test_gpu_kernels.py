@@ -333,7 +333,7 @@ def test_gru_cell_fused_equals_three_call_form_and_oracle(K, R, E, H):
 
 
 @pytest.mark.parametrize('M,N,Kd', [(300, 700, 64), (2049, 1000, 256), (128, 256, 16), (5, 32000, 256), (1000, 515, 512), (260, 520, 1024)])
-@pytest.mark.parametrize('variant', [0, 2, 3])
+@pytest.mark.parametrize('variant', [0, 2, 3, 4])
 def test_gemm_dma_k_major_activations_bit_exact(K, M, N, Kd, variant):
     """Both operands staged by LDS-DMA (activations given k-major): the same fma chain per element as the register-staged
     kernel and the oracle, so ``==``; columns of the k-major operand beyond M hold garbage on purpose."""
@@ -350,6 +350,29 @@ def test_gemm_dma_k_major_activations_bit_exact(K, M, N, Kd, variant):
     K.gemm_dma(at, wd[:, :N], dev(b), out, M, variant=variant)
     assert np.array_equal(out[:M, :N].cpu().numpy(), C.gemm(a, w, b))
     assert (out[M:] == 7.0).all() and (out[:, N:] == 7.0).all()
+
+
+@pytest.mark.parametrize('M,N,Kd', [(2049, 32000, 256), (15676, 32000, 256), (700, 31999 + 1, 1024), (4100, 5000, 64)])
+def test_gemm_dma_persistent_form_walks_many_tiles(K, M, N, Kd):
+    """The persistent variant when every workgroup walks several tiles (full and partial ones, the ring of stages running on
+    across them, a tile's stores in flight under the next tile): bit for bit the one-tile-per-workgroup kernel, which is
+    pinned to the oracle above; the bytes around C stay untouched."""
+    g = torch.Generator(device='cuda').manual_seed(M + N)
+    a = torch.randn((M, Kd), device='cuda', generator=g)
+    w = torch.randn((Kd, N), device='cuda', generator=g) / Kd ** 0.5
+    b = torch.randn(N, device='cuda', generator=g)
+    ld = (M + 127) // 128 * 128
+    at = torch.full((Kd, ld), 1e30, device='cuda')
+    at[:, :M] = a.t()
+    ref = torch.full((M + 1, N + 4), 7.0, device='cuda')
+    out = torch.full((M + 1, N + 4), 7.0, device='cuda')
+    K.gemm_dma(at, w, b, ref, M, n_cols=N, variant=3)
+    for _ in range(2):
+        K.gemm_dma(at, w, b, out, M, n_cols=N, variant=4)
+    assert torch.equal(out, ref)
+    K.gemm_dma(at, w, None, ref, M, n_cols=N, variant=3)
+    K.gemm_dma(at, w, None, out, M, n_cols=N, variant=4)
+    assert torch.equal(out, ref)
 
 
 @pytest.mark.parametrize('R,d', [(130, 256), (64, 512), (1, 32), (1000, 64)])

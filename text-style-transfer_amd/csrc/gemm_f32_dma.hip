@@ -211,6 +211,181 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __res
         }
 }
 
+// Persistent form of the 128 x 256 tile (plain product, nontemporal stores): at most two workgroups per CU walk the tiles
+// slot, slot + slots, ... of their XCD's contiguous range, and the ring of stages runs on ACROSS tiles: while the last NST - 1
+// stages of a tile are multiplied, the stages requested are the first ones of the next tile, so a tile starts with its operands
+// in LDS and its bias in registers (requested a tile ahead), and the 128 stores per lane of a tile's epilogue drain under the
+// next tile's k loop.  Vector-memory operations of a wave complete in issue order and vmcnt saturates at 63: while the stage
+// waited for is older than a full tile's stores, "all but the 63 youngest operations" covers it; after a partial tile (fewer
+// stores) the strict count is used.  Same fma chain per element as gemm_f32_dma_kernel.
+template <int BK, int NST>
+__global__ __launch_bounds__(256, 2) void gemm_f32_dma_persist_kernel(const float* __restrict__ AT, int64_t ldat, const float* __restrict__ W,
+                                                                      int64_t ldw, const float* __restrict__ bias, float* C, int64_t ldc, int M,
+                                                                      int N, int K, int tiles_m, int tiles_n) {
+    constexpr int TM = 128, WVN = 2, WTM = 2, WTN = 4;
+    constexpr int A_BYTES = BK * TM * 4, B_BYTES = BK * TN * 4, STAGE = A_BYTES + B_BYTES;
+    constexpr int NA = A_BYTES / 4096, NB = B_BYTES / 4096, NDMA = NA + NB;
+    constexpr int LPR = TM / 4, RPP = 64 / LPR;
+    constexpr int NBIAS = WTN;                       // bias loads of a lane per tile
+    static_assert(NDMA * (NST - 3) + NBIAS < 63 && NST >= 4, "counted waits");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WVN, wn = wave % WVN;
+    const int nkt = K / BK;
+
+    // this workgroup's tiles: XCD (bid & 7) owns a contiguous range of the m-grouped tile order, slot bid >> 3 takes every
+    // (gridDim.x / 8)-th tile of it
+    const int nwg = tiles_m * tiles_n, bid = blockIdx.x, slots = gridDim.x >> 3;
+    const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
+    const int lb_begin = xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q;
+    const int lb_end = lb_begin + q + (xcd < rem ? 1 : 0);
+    const int lb0 = lb_begin + (bid >> 3);
+    if (lb0 >= lb_end) return;                       // workgroup-uniform
+    const int n_tiles = (lb_end - lb0 + slots - 1) / slots;
+    const int n_stages = n_tiles * nkt;
+
+    auto tile_of = [&](int l, int& m0, int& n0) {
+        const int per_group = GROUP_M * tiles_n;
+        const int first_m = (l / per_group) * GROUP_M;
+        const int gsz = min(tiles_m - first_m, GROUP_M);
+        m0 = (first_m + (l % per_group) % gsz) * TM;
+        n0 = ((l % per_group) / gsz) * TN;
+    };
+
+    // ---- request side: the stream of stages (tile by tile, k ascending) is requested NST - 1 stages ahead of its use
+    int lb_r = lb0, kt_r = 0, slot_r = 0;
+    const float *a_src, *w_src;
+    auto locate_r = [&]() {
+        int m0, n0;
+        tile_of(lb_r, m0, n0);
+        a_src = AT + (int64_t)(RPP * wave + lane / LPR) * ldat + m0 + 4 * (lane % LPR);
+        w_src = W + (int64_t)wave * ldw + min(n0 + 4 * lane, (int)ldw - 4);
+    };
+    auto request_stage = [&]() {
+        unsigned char* base = smem + slot_r * STAGE + wave * 1024;
+        const int k0 = kt_r * BK;
+#pragma unroll
+        for (int j = 0; j < NA; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src + (int64_t)(k0 + 4 * RPP * j) * ldat), (lds_void_t*)(base + j * 4096), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(w_src + (int64_t)(k0 + 4 * j) * ldw), (lds_void_t*)(base + A_BYTES + j * 4096), 16, 0, 0);
+        slot_r = slot_r + 1 == NST ? 0 : slot_r + 1;
+        if (++kt_r == nkt) {
+            kt_r = 0;
+            lb_r += slots;
+            if (lb_r < lb_end) locate_r();
+        }
+    };
+    // the bias of a tile, requested a tile ahead with loads the compiler does not track (it would wait for them, and for
+    // every DMA in front of them, at once): lane owns columns n0 + wn * 128 + 32 j + (lane & 31)
+    float nbias[NBIAS];
+    auto request_bias = [&](int l) {
+        int m0, n0;
+        tile_of(l, m0, n0);
+#pragma unroll
+        for (int j = 0; j < NBIAS; ++j) {
+            const float* p = bias + min(n0 + wn * 32 * WTN + j * 32 + (lane & 31), N - 1);
+            asm volatile("global_load_dword %0, %1, off" : "=v"(nbias[j]) : "v"(p) : "memory");
+        }
+    };
+
+    const int khalf = lane >> 5;
+    const uint32_t lds_base = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const uint32_t a_off = lds_base + (khalf * TM + wm * 32 * WTM + (lane & 31)) * 4;
+    const uint32_t b_off = lds_base + A_BYTES + (khalf * TN + wn * 32 * WTN + (lane & 31)) * 4;
+    float fa[2][WTM], fb[2][WTN];
+    auto read_step = [&](int set, uint32_t as, uint32_t bs) {
+#pragma unroll
+        for (int i = 0; i < WTM; ++i) asm volatile("ds_read_b32 %0, %1" : "=v"(fa[set][i]) : "v"(as + i * 128));
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) asm volatile("ds_read_b32 %0, %1" : "=v"(fb[set][j]) : "v"(bs + j * 128));
+    };
+    auto lds_wait = [&]() {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    f32x16 acc[WTM][WTN];
+
+    locate_r();
+    if (bias != nullptr) request_bias(lb0);
+#pragma unroll
+    for (int p = 0; p < NST - 1; ++p)
+        if (p < n_stages) request_stage();
+    if (n_stages >= NST - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NST - 2)) : "memory");   // stage 0 and the bias
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    read_step(0, a_off, b_off);
+
+    constexpr int STEPS = BK / 2;
+    int st = 0, g = 0;                               // slot and index (in this workgroup's stream) of the stage being multiplied
+    bool stores_behind = false;                      // a full tile's stores were issued in front of this tile
+    for (int lb = lb0; lb < lb_end; lb += slots) {
+        int m0, n0;
+        tile_of(lb, m0, n0);
+#pragma unroll
+        for (int j = 0; j < WTN; ++j) {
+            const float b = bias != nullptr ? nbias[j] : 0.0f;
+#pragma unroll
+            for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = b;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const bool bias_behind = bias != nullptr && lb + slots < lb_end;
+        if (bias_behind) request_bias(lb + slots);
+        for (int kt = 0; kt < nkt; ++kt, ++g) {
+            const int st_next = st + 1 == NST ? 0 : st + 1;
+            const uint32_t as = a_off + st * STAGE, bs = b_off + st * STAGE;
+#pragma unroll
+            for (int s = 0; s < STEPS; ++s) {
+                lds_wait();
+                if (s + 1 < STEPS) read_step((s + 1) & 1, as + (s + 1) * (2 * TM * 4), bs + (s + 1) * (2 * TN * 4));
+                else if (g + 1 < n_stages) read_step((s + 1) & 1, a_off + st_next * STAGE, b_off + st_next * STAGE);
+                __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+                for (int i = 0; i < WTM; ++i)
+#pragma unroll
+                    for (int j = 0; j < WTN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s & 1][i], fb[s & 1][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_s_setprio(0);
+                if (s == STEPS / 2 - 1) {
+                    // stage g + 1 must have landed: NST - 3 younger stages may be in flight, plus what was issued behind it at
+                    // the start of this tile (the previous tile's stores, the next tile's bias loads)
+                    if (g + NST - 2 < n_stages) {
+                        if (kt <= NST - 3 && stores_behind) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+                        else if (kt <= NST - 3 && bias_behind) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NST - 3) + NBIAS) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NST - 3)) : "memory");
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    }
+                    __builtin_amdgcn_s_barrier();
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (g + NST - 1 < n_stages) request_stage();
+                }
+            }
+            st = st_next;
+        }
+        // epilogue: lane owns column col of 16 rows per 32 x 32 block (rows (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5))
+        const bool full_tile = m0 + TM <= M && n0 + TN <= N;
+#pragma unroll
+        for (int i = 0; i < WTM; ++i)
+#pragma unroll
+            for (int j = 0; j < WTN; ++j) {
+                const int col = n0 + wn * 32 * WTN + j * 32 + (lane & 31);
+                const int row0 = m0 + wm * 32 * WTM + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + (r & 3) + 8 * (r >> 2);
+                    if (full_tile || (col < N && row < M)) __builtin_nontemporal_store(acc[i][j][r], &C[(int64_t)row * ldc + col]);
+                }
+            }
+        stores_behind = full_tile;
+    }
+}
+
 // y^T = LayerNorm(x)^T: the statistics and the affine map of layernorm_kernel (64 interleaved partial sums, xor-butterfly;
 // one wave per row), the normalised rows of a 64-row block collected in LDS and written k-major, yT[k][r], 64 consecutive
 // rows (256 bytes) per wave-instruction.
@@ -301,6 +476,13 @@ extern "C" int tst_gemm_dma_f32(const float* AT, int64_t ldat, const float* Wt, 
         case 1: launch_plain128<8, 4>(AT, ldat, Wt, ldw, bias, C, ldc, M, N, K, st); break;
         case 0: launch_plain128<16, 3>(AT, ldat, Wt, ldw, bias, C, ldc, M, N, K, st); break;
         case 3: launch_plain128<8, 6, true>(AT, ldat, Wt, ldw, bias, C, ldc, M, N, K, st); break;
+        case 4: {   // persistent: two workgroups per CU, a multiple of 8 so that every XCD has the same slots
+            const int64_t nwg = tiles_m * tiles_n;
+            const unsigned grid = (unsigned)(nwg >= 512 ? 512 : (nwg + 7) / 8 * 8);
+            hipLaunchKernelGGL((gemm_f32_dma_persist_kernel<8, 6>), dim3(grid), dim3(256), 0, st, AT, ldat, Wt, ldw, bias, C, ldc, (int)M, (int)N,
+                               (int)K, (int)tiles_m, (int)tiles_n);
+            break;
+        }
         default: launch_plain128<8, 6>(AT, ldat, Wt, ldw, bias, C, ldc, M, N, K, st); break;
     }
     return tst_after_launch("tst_gemm_dma_f32");

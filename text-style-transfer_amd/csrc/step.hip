@@ -38,6 +38,12 @@ struct StepCtx {
 // TST_TFM_CHAIN=1 in the environment (measurements): large fp32 steps of a d_model = 256 decoder with cross-attention run the
 // residual product -> LayerNorm -> next product chains as one kernel each (tst_chain_f32).  Same results; measured slower
 // than the separate launches at most row counts (a 64-row tile per CU: rounds of 16384 rows), hence off by default.
+// TST_VOCAB_VARIANT=<n> in the environment (measurements): the tst_gemm_dma_f32 variant of the vocabulary projection
+int tst_vocab_variant() {
+    static const int v = [] { const char* e = getenv("TST_VOCAB_VARIANT"); return (e != nullptr && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : 3; }();
+    return v;
+}
+
 bool tst_tfm_chain() {
     static const bool v = [] { const char* e = getenv("TST_TFM_CHAIN"); return e != nullptr && e[0] == '1'; }();
     return v;
@@ -154,7 +160,7 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
         TST_REQUIRE(m->wout != nullptr, TST_ERR_ARG, "tst_tfm_step_run: null output projection");
         if (dma_vocab)
             TST_TRY(tst_gemm_dma_f32(m->ht, m->ld_ht, (const float*)m->wout, m->ld_wout, m->bout, (float*)m->logits, m->ld_logits, R, m->V, d,
-                                     3, stream));   // nontemporal stores: the logits leave the caches before they are read
+                                     tst_vocab_variant(), stream));   // nontemporal stores: the logits leave the caches before they are read
         else if (c.bf16 && m->part != nullptr && tst_vocab_stats_ok(R, m->V, d))
             // the selection pass of a beam search reads these statistics instead of the rows (tst_select_step_run)
             TST_TRY(tst_vocabproj_stats_bf16(m->h, d, m->wout, m->ld_wout, m->bout, m->logits, m->ld_logits, R, m->V, d, m->part,

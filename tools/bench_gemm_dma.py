@@ -34,7 +34,7 @@ for M in [int(a) for a in sys.argv[1:]] or [32768, 15676, 8192, 4096, 2048]:
     t0 = med(lambda: K.gemm(a, w, b, ref, M))
     fl = 2.0 * M * N * Kd
     line = 'M=%d  register-staged %.3f ms %.1f TF' % (M, t0, fl / t0 / 1e9)
-    for v in (0, 1, 2, 3):
+    for v in (0, 1, 2, 3, 4):
         out = torch.zeros((M, N), device='cuda')
         t1 = med(lambda: K.gemm_dma(at, w, b, out, M, variant=v))
         line += ' | dma v%d %.3f ms %.1f TF %s' % (v, t1, fl / t1 / 1e9, 'same bits' if torch.equal(out, ref) else 'DIFFERENT')
