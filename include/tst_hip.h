@@ -73,7 +73,7 @@ int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw,
  * K % 16 == 0; ldat a multiple of 4 and >= M rounded up to a multiple of 128 (columns of AT beyond M may hold anything);
  * ldw % 4 == 0, ldw >= N; AT and Wt 16-byte aligned.  variant: 0 = tiles of 16 k in a ring of 3, 1 = 8 k x 4, 2 = 8 k x 6,
  * 3 = 8 k x 6 with nontemporal stores of C, 4 = 3 as a persistent kernel (two workgroups per CU walk the tiles, the ring of
- * stages runs on across tiles) (tuning; same results). */
+ * stages runs on across tiles), 5 = 256 x 256 tiles on 8 waves (needs ldat >= M rounded up to 256) (tuning; same results). */
 int tst_gemm_dma_f32(const float* AT, int64_t ldat, const float* Wt, int64_t ldw, const float* bias, float* C, int64_t ldc,
                      int64_t M, int64_t N, int64_t K, int variant, void* stream);
 

@@ -27,14 +27,15 @@ constexpr int TN = 256, GROUP_M = 16;
 // OUT_T: the product is computed transposed (operands swapped: the same fma chain per element), a lane then owns a ROW
 // and its 16 registers are 16 columns, and C (and res) are K-MAJOR, C[n][m]: 32 lanes store 128 contiguous bytes.
 template <int TM, int WVM, int WVN, int BK, int NST, bool HAS_RES, bool RELU, bool OUT_T, bool NT_STORE = false>
-__global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __restrict__ AT, int64_t ldat, const float* __restrict__ W,
+__global__ __launch_bounds__(64 * WVM * WVN, (WVM * WVN == 4 ? 2 : 1)) void gemm_f32_dma_kernel(const float* __restrict__ AT, int64_t ldat, const float* __restrict__ W,
                                                               int64_t ldw, const float* __restrict__ bias, const float* res, int64_t ldr,
                                                               float* C, int64_t ldc, int M, int N, int K, int tiles_m, int tiles_n) {
     constexpr int WTM = TM / WVM / 32, WTN = TN / WVN / 32;
     constexpr int A_BYTES = BK * TM * 4, B_BYTES = BK * TN * 4, STAGE = A_BYTES + B_BYTES;
-    constexpr int NA = A_BYTES / 4096, NB = B_BYTES / 4096, NDMA = NA + NB;   // wave-instructions per wave and tile
+    constexpr int NWV = WVM * WVN, PIECE = 1024 * NWV;                          // a round of 1 KiB pieces, one per wave
+    constexpr int NA = A_BYTES / PIECE, NB = B_BYTES / PIECE, NDMA = NA + NB;   // wave-instructions per wave and tile
     constexpr int LPR = TM / 4, RPP = 64 / LPR;                               // lanes per A row, A rows per 1 KiB piece
-    static_assert(WVM * WVN == 4 && A_BYTES % 4096 == 0 && B_BYTES % 4096 == 0 && NST >= 3 && WTM >= 1 && WTN >= 1, "tile shape");
+    static_assert((NWV == 4 || NWV == 8) && A_BYTES % PIECE == 0 && B_BYTES % PIECE == 0 && NST >= 3 && WTM >= 1 && WTN >= 1, "tile shape");
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NST * STAGE];
 
     const int nwg = tiles_m * tiles_n;
@@ -53,7 +54,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __res
     const int wm = wave / WVN, wn = wave % WVN;
 
     // DMA sources.  A piece (1 KiB) is RPP k-rows of the A tile (TM floats each): lane l -> k = RPP p + l / LPR,
-    // m = 4 (l % LPR); a piece of the Wt tile is one k-row (256 floats): lane l -> n = 4 l.  Wave w moves pieces w, w + 4, ...
+    // m = 4 (l % LPR); a piece of the Wt tile is one k-row (256 floats): lane l -> n = 4 l.  Wave w moves pieces w, w + NWV, ...
     // The rows of AT are ldat >= tiles_m * TM floats long, so the tile's columns always exist (columns beyond M hold
     // stale values whose products are never stored); columns of Wt beyond ldw are clamped.
     const float* a_src = AT + (int64_t)(RPP * wave + lane / LPR) * ldat + m0 + 4 * (lane % LPR);
@@ -62,11 +63,11 @@ __global__ __launch_bounds__(256, 2) void gemm_f32_dma_kernel(const float* __res
         unsigned char* base = smem + st * STAGE + wave * 1024;
 #pragma unroll
         for (int j = 0; j < NA; ++j)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src + (int64_t)(k0 + 4 * RPP * j) * ldat), (lds_void_t*)(base + j * 4096), 16, 0,
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(a_src + (int64_t)(k0 + NWV * RPP * j) * ldat), (lds_void_t*)(base + j * PIECE), 16, 0,
                                              0);
 #pragma unroll
         for (int j = 0; j < NB; ++j)
-            __builtin_amdgcn_global_load_lds((glb_void_t*)(w_src + (int64_t)(k0 + 4 * j) * ldw), (lds_void_t*)(base + A_BYTES + j * 4096), 16, 0,
+            __builtin_amdgcn_global_load_lds((glb_void_t*)(w_src + (int64_t)(k0 + NWV * j) * ldw), (lds_void_t*)(base + A_BYTES + j * PIECE), 16, 0,
                                              0);
     };
 
@@ -450,6 +451,15 @@ extern "C" int tst_layernorm_t_f32(const float* x, const float* gamma, const flo
 
 namespace {
 
+// 256 x 256 tiles on 8 waves (4 x 2, each 64 x 128 as in the 128-row tile): half the staged bytes per MFMA, one workgroup per CU
+template <int BK, int NST>
+void launch_plain256(const float* AT, int64_t ldat, const float* Wt, int64_t ldw, const float* bias, float* C, int64_t ldc, int64_t M,
+                     int64_t N, int64_t K, hipStream_t st) {
+    const int64_t tiles_m = (M + 255) / 256, tiles_n = (N + TN - 1) / TN;
+    hipLaunchKernelGGL((gemm_f32_dma_kernel<256, 4, 2, BK, NST, false, false, false, true>), dim3((unsigned)(tiles_m * tiles_n)), dim3(512), 0, st,
+                       AT, ldat, Wt, ldw, bias, nullptr, 0, C, ldc, (int)M, (int)N, (int)K, (int)tiles_m, (int)tiles_n);
+}
+
 template <int BK, int NST, bool NT_STORE = false>
 void launch_plain128(const float* AT, int64_t ldat, const float* Wt, int64_t ldw, const float* bias, float* C, int64_t ldc, int64_t M,
                      int64_t N, int64_t K, hipStream_t st) {
@@ -476,6 +486,10 @@ extern "C" int tst_gemm_dma_f32(const float* AT, int64_t ldat, const float* Wt, 
         case 1: launch_plain128<8, 4>(AT, ldat, Wt, ldw, bias, C, ldc, M, N, K, st); break;
         case 0: launch_plain128<16, 3>(AT, ldat, Wt, ldw, bias, C, ldc, M, N, K, st); break;
         case 3: launch_plain128<8, 6, true>(AT, ldat, Wt, ldw, bias, C, ldc, M, N, K, st); break;
+        case 5:     // 256-row tiles: AT must have its rows padded to a multiple of 256 columns
+            TST_REQUIRE(ldat >= (M + 255) / 256 * 256, TST_ERR_ARG, "tst_gemm_dma_f32: variant 5 needs ldat >= M rounded up to 256");
+            launch_plain256<8, 6>(AT, ldat, Wt, ldw, bias, C, ldc, M, N, K, st);
+            break;
         case 4: {   // persistent: two workgroups per CU, a multiple of 8 so that every XCD has the same slots
             const int64_t nwg = tiles_m * tiles_n;
             const unsigned grid = (unsigned)(nwg >= 512 ? 512 : (nwg + 7) / 8 * 8);

@@ -27,14 +27,14 @@ w = torch.randn((Kd, N), device='cuda', generator=g) / 16
 b = torch.randn(N, device='cuda', generator=g)
 for M in [int(a) for a in sys.argv[1:]] or [32768, 15676, 8192, 4096, 2048]:
     a = torch.randn((M, Kd), device='cuda', generator=g)
-    ld = (M + 127) // 128 * 128
+    ld = (M + 255) // 256 * 256
     at = torch.zeros((Kd, ld), device='cuda')
     at[:, :M] = a.t()
     ref = torch.empty((M, N), device='cuda')
     t0 = med(lambda: K.gemm(a, w, b, ref, M))
     fl = 2.0 * M * N * Kd
     line = 'M=%d  register-staged %.3f ms %.1f TF' % (M, t0, fl / t0 / 1e9)
-    for v in (0, 1, 2, 3, 4):
+    for v in (2, 3, 4, 5):
         out = torch.zeros((M, N), device='cuda')
         t1 = med(lambda: K.gemm_dma(at, w, b, out, M, variant=v))
         line += ' | dma v%d %.3f ms %.1f TF %s' % (v, t1, fl / t1 / 1e9, 'same bits' if torch.equal(out, ref) else 'DIFFERENT')
