@@ -37,7 +37,7 @@ extern "C" {
  * tst_select_step.n_sent_dev, tst_pack_sources, tst_scatter_rows_f32;
  * 105 = 104 + tst_vocab_stats_ok, tst_vocabproj_stats_bf16, tst_topk_from_stats_bf16, tst_tfm_step.part / n_slices,
  * tst_select_step.part / n_slices / stats_k, tst_gru_cell_fused_t_f32, tst_gru_step.ht / ld_ht;
- * 106 = 105 + tst_chain_ok, tst_chain_f32 (additions only). */
+ * 106 = 105 + tst_chain_ok, tst_chain_f32, tst_gemm_res_ln_ok, tst_gemm_res_ln_bf16 (additions only). */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
@@ -133,6 +133,15 @@ int tst_add_rows_f32(float* x, const float* z, const int32_t* idx, int64_t R, in
 int tst_gemm_mfma_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, const float* res,
                        int64_t ldr, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, int out_bf16,
                        void* stream);
+
+/* x[M][512] += A * W^T + bias (tst_gemm_mfma_bf16 with res == C == x, fp32) and h = LayerNorm(x) rounded to bf16
+ * (tst_layernorm_f32_bf16) as ONE kernel on whole-row tiles of 128 x 512: the LayerNorm behind a residual product of a
+ * model_size = 512 bf16 decoder (the model called at /root/reference/src/trainers/lm_trainer.py:72-74,86) without its launch and
+ * without reading x back.  Bit-identical to the two calls.  N must be 512, K a multiple of 32 and >= 96 (tst_gemm_res_ln_ok);
+ * x is [M][512] contiguous; alignment as for tst_gemm_mfma_bf16. */
+int tst_gemm_res_ln_ok(int64_t M, int64_t N, int64_t K);
+int tst_gemm_res_ln_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, const float* gamma,
+                         const float* beta, float eps, void* h, int64_t ldh, int64_t M, int64_t N, int64_t K, void* stream);
 
 /* One decoder self-attention step with an incremental KV cache.
  * cache: [n_pos][slab_rows][3*d] fp32, the fused q|k|v projection output of every past step; the rows of

@@ -432,3 +432,26 @@ def test_dtype_and_return_logits_keys(T):
     gru = T.RNNDecoder(32, 32, vocab_g)
     with pytest.raises(ValueError):
         T.InferenceState({'model': gru, 'inputs': torch.zeros(2, 32).cuda(), 'vocab': vocab_g, 'dtype': 'bf16'}).inference()
+
+
+@pytest.mark.parametrize('M,Kd', [(1, 512), (127, 512), (129, 2048), (1000, 512), (4097, 2048), (20000, 512)])
+def test_residual_product_with_layernorm_epilogue_equals_the_two_entry_points(M, Kd):
+    """tst_gemm_res_ln_bf16 (whole-row 128 x 512 tiles, LayerNorm of the fresh rows in the epilogue) against
+    tst_gemm_mfma_bf16 with a residual followed by tst_layernorm_f32_bf16: x and h bit for bit; rows beyond M untouched."""
+    import tst_amd  # noqa: F401
+    from tst_amd import kernels as K
+    g = torch.Generator(device='cuda').manual_seed(M + Kd)
+    a = torch.randn((M, Kd), device='cuda', generator=g).to(torch.bfloat16)
+    w = (torch.randn((512, Kd), device='cuda', generator=g) / Kd ** 0.5).to(torch.bfloat16)
+    bias = torch.randn(512, device='cuda', generator=g)
+    x0 = torch.randn((M + 2, 512), device='cuda', generator=g) * 2 + 0.3
+    gam, bet = torch.randn(512, device='cuda', generator=g), torch.randn(512, device='cuda', generator=g)
+    x_ref = x0.clone()
+    h_ref = torch.full((M + 2, 512), 7.0, device='cuda', dtype=torch.bfloat16)
+    K.gemm_bf16(a, w, bias, x_ref, M, res=x_ref)
+    K.layernorm(x_ref, gam, bet, h_ref, M)
+    x = x0.clone()
+    h = torch.full((M + 2, 512), 7.0, device='cuda', dtype=torch.bfloat16)
+    K.gemm_res_ln_bf16(a, w, bias, x, gam, bet, h, M)
+    assert torch.equal(x, x_ref)
+    assert torch.equal(h.view(torch.int16), h_ref.view(torch.int16))

@@ -111,6 +111,8 @@ _PROTOS = {
     'tst_add_rows_f32': ([c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_gemm_mfma_bf16': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp],
                            c_int),
+    'tst_gemm_res_ln_ok': ([c_i64, c_i64, c_i64], c_int),
+    'tst_gemm_res_ln_bf16': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_vocab_stats_ok': ([c_i64, c_i64, c_i64], c_int),
     'tst_vocabproj_stats_bf16': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_i64, c_vp], c_int),
     'tst_topk_from_stats_bf16': ([c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp, c_vp, c_vp, c_vp], c_int),

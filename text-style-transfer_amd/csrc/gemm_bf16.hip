@@ -206,12 +206,21 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int DK = 32;   // k per tile of the DMA kernel
 
-template <int WVM, int WVN, int WTM, int WTN, int NST, bool OUT_BF16, bool HAS_RES, bool RELU>
+// LayerNorm of the rows the tile has just produced, for the whole-row tile (128 x 512) of a residual product: see LN below
+struct LnOut {
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    float eps = 0.0f;
+    __bf16* h = nullptr;
+    int64_t ldh = 0;
+};
+
+template <int WVM, int WVN, int WTM, int WTN, int NST, bool OUT_BF16, bool HAS_RES, bool RELU, bool LN = false>
 __global__ __launch_bounds__(64 * WVM * WVN) void gemm_bf16_dma_kernel(const __bf16* __restrict__ A, int64_t lda,
                                                             const __bf16* __restrict__ W, int64_t ldw,
                                                             const float* __restrict__ bias, const float* res, int64_t ldr,
                                                             void* Cout, int64_t ldc, int M, int N, int K, int tiles_m,
-                                                            int tiles_n) {
+                                                            int tiles_n, const LnOut ln = LnOut{}) {
     // workgroup tile: WVM x WVN waves, each with WTM x WTN MFMA tiles of 32 x 32
     constexpr int NWV = WVM * WVN, TM = 32 * WTM * WVM, TN = 32 * WTN * WVN;
     constexpr int STAGE = (TM + TN) * 64;                // bytes of one stage: A rows then W rows, 64 bytes each
@@ -383,6 +392,10 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_bf16_dma_kernel(const __b
                         }
                     }
                 }
+                if (LN) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = v[r];
+                }
                 if (OUT_BF16) {
                     // pack each group of 4 columns to 8 bytes and put it into the wave's LDS image [64 rows][32 WTN columns]
                     unsigned char* img = smem + wave * IMG + (ii * 32 + (lane & 31)) * OUT_LD + (j * 32 + 4 * h) * 2;
@@ -437,6 +450,103 @@ __global__ __launch_bounds__(64 * WVM * WVN) void gemm_bf16_dma_kernel(const __b
                 }
             }
         }
+    }
+    // LN: the tile holds whole rows of N = 512 (x = acc + res is in the accumulators): h = LayerNorm(x) in bf16, with the
+    // statistics formed in exactly the order of layernorm_kernel, whose lane p owns the 16-byte chunks p and p + 64 of a row and
+    // sums chunk p's four elements, then chunk p + 64's, before the xor-butterfly 32 .. 1 over the 64 partial sums.  Here a lane
+    // owns rows (i) and chunk c = wn * 32 + j * 8 + 2 g + h: waves wn = 0, 1 start the partial sums (PA), waves 2, 3 continue
+    // them with their chunks (PB), then every wave combines the two halves (level 32), j (16, 8), g (4, 2) and the wave halves (1).
+    if constexpr (LN) {
+        static_assert(WVM == 2 && WVN == 4 && WTM == 2 && WTN == 4 && HAS_RES && !OUT_BF16 && !RELU, "LN: the 128 x 512 residual tile");
+        float* PA = reinterpret_cast<float*>(smem);                     // [wm][wn & 1][i][j * 4 + g][lane]
+        float* PB = PA + 2 * 2 * 2 * 16 * 64;
+        const int pmine = ((wm * 2 + (wn & 1)) * 2) * 16 * 64 + lane;
+        float mean[2] = {0.0f, 0.0f}, rstd[2] = {0.0f, 0.0f};
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            float q[2][16];
+            auto extend = [&]() {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            float p = q[i][j * 4 + g];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                if (pass == 0) {
+                                    p = p + acc[i][j][4 * g + e];
+                                } else {
+                                    const float t = acc[i][j][4 * g + e] - mean[i];
+                                    p = __builtin_fmaf(t, t, p);
+                                }
+                            }
+                            q[i][j * 4 + g] = p;
+                        }
+            };
+            if (wn < 2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) q[i][c] = 0.0f;
+                extend();
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) PA[pmine + (i * 16 + c) * 64] = q[i][c];
+            }
+            __syncthreads();
+            if (wn >= 2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) q[i][c] = PA[pmine + (i * 16 + c) * 64];
+                extend();
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int c = 0; c < 16; ++c) PB[pmine + (i * 16 + c) * 64] = q[i][c];
+            }
+            __syncthreads();
+            const int p0 = ((wm * 2 + 0) * 2) * 16 * 64 + lane, p1 = ((wm * 2 + 1) * 2) * 16 * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float s1[16];
+#pragma unroll
+                for (int c = 0; c < 16; ++c) s1[c] = PB[p0 + (i * 16 + c) * 64] + PB[p1 + (i * 16 + c) * 64];   // level 32
+                float s2[8];
+#pragma unroll
+                for (int c = 0; c < 8; ++c) s2[c] = s1[c] + s1[c + 8];                                            // level 16: j ^ 2
+                float s3[4];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) s3[g] = s2[g] + s2[4 + g];                                            // level 8: j ^ 1
+                const float s4a = s3[0] + s3[2], s4b = s3[1] + s3[3];                                             // level 4: g ^ 2
+                float v = s4a + s4b;                                                                              // level 2: g ^ 1
+                v = v + lane_xor<32>(v);                                                                          // level 1: h
+                if (pass == 0) mean[i] = v / 512.0f;
+                else rstd[i] = 1.0f / sqrtf(v / 512.0f + ln.eps);
+            }
+        }
+        const int h2 = lane >> 5;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int col = wn * 128 + j * 32 + 8 * g + 4 * h2;
+                const float4 gg = *reinterpret_cast<const float4*>(ln.gamma + col), bb = *reinterpret_cast<const float4*>(ln.beta + col);
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int m = m0 + wm * 64 + i * 32 + (lane & 31);
+                    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+                    union { bf16x4 b; uint2 u; } cv;
+                    cv.b[0] = (__bf16)__builtin_fmaf((acc[i][j][4 * g] - mean[i]) * rstd[i], gg.x, bb.x);
+                    cv.b[1] = (__bf16)__builtin_fmaf((acc[i][j][4 * g + 1] - mean[i]) * rstd[i], gg.y, bb.y);
+                    cv.b[2] = (__bf16)__builtin_fmaf((acc[i][j][4 * g + 2] - mean[i]) * rstd[i], gg.z, bb.z);
+                    cv.b[3] = (__bf16)__builtin_fmaf((acc[i][j][4 * g + 3] - mean[i]) * rstd[i], gg.w, bb.w);
+                    if (m < M) *reinterpret_cast<uint2*>(ln.h + (int64_t)m * ln.ldh + col) = cv.u;
+                }
+            }
     }
 }
 
@@ -795,6 +905,29 @@ extern "C" int tst_gemm_mfma_bf16(const void* A, int64_t lda, const void* W, int
     return tst_after_launch("tst_gemm_mfma_bf16");
 }
 
+
+extern "C" int tst_gemm_res_ln_ok(int64_t M, int64_t N, int64_t K) {
+    return (M > 0 && M < (1ll << 31) - 128 && N == 512 && K >= 96 && K % DK == 0 && K < (1ll << 31)) ? 1 : 0;
+}
+
+extern "C" int tst_gemm_res_ln_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, const float* gamma,
+                                    const float* beta, float eps, void* h, int64_t ldh, int64_t M, int64_t N, int64_t K, void* stream) {
+    TST_REQUIRE(A && W && x && gamma && beta && h, TST_ERR_ARG, "tst_gemm_res_ln_bf16: null pointer");
+    TST_REQUIRE(M >= 0, TST_ERR_ARG, "tst_gemm_res_ln_bf16: bad sizes");
+    if (M == 0) return TST_OK;
+    TST_REQUIRE(tst_gemm_res_ln_ok(M, N, K), TST_ERR_UNSUPPORTED, "tst_gemm_res_ln_bf16: needs N == 512 and K a multiple of 32, at least 96 (got N=%lld K=%lld)",
+                (long long)N, (long long)K);
+    TST_REQUIRE(lda % 8 == 0 && ldw % 8 == 0 && ldh % 4 == 0 && lda >= K && ldw >= K && ldh >= N, TST_ERR_ARG,
+                "tst_gemm_res_ln_bf16: lda, ldw multiples of 8, ldh of 4; lda >= K, ldw >= K, ldh >= N");
+    TST_REQUIRE(tst_aligned16(A) && tst_aligned16(W) && tst_aligned16(x) && tst_aligned16(bias) && tst_aligned16(gamma) && tst_aligned16(beta) &&
+                    ((uintptr_t)h & 7u) == 0, TST_ERR_ARG, "tst_gemm_res_ln_bf16: A, W, x, bias, gamma, beta 16-byte aligned, h 8-byte aligned");
+    LnOut ln;
+    ln.gamma = gamma; ln.beta = beta; ln.eps = eps; ln.h = (__bf16*)h; ln.ldh = ldh;
+    const int64_t tm = (M + 127) / 128;
+    hipLaunchKernelGGL((gemm_bf16_dma_kernel<2, 4, 2, 4, 3, false, true, false, true>), dim3((unsigned)tm), dim3(512), 0, (hipStream_t)stream,
+                       (const __bf16*)A, lda, (const __bf16*)W, ldw, bias, x, N, x, N, (int)M, (int)N, (int)K, (int)tm, 1, ln);
+    return tst_after_launch("tst_gemm_res_ln_bf16");
+}
 
 // The shapes for which the vocabulary projection can emit its per-slice statistics: those that tst_gemm_mfma_bf16 runs on the
 // persistent 256 x 256 kernel (a bf16 result of at least 4096 columns and 256 tiles, K a multiple of 32 and at least 96)

@@ -44,6 +44,13 @@ int tst_vocab_variant() {
     return v;
 }
 
+// TST_BF16_LN_FUSE=<rows> in the environment (measurements): bf16 steps of a model_size = 512 decoder without cross-attention with
+// at least that many rows run every residual product together with the LayerNorm behind it (tst_gemm_res_ln_bf16).  0 / unset: never.
+int64_t tst_bf16_ln_fuse_rows() {
+    static const int64_t v = [] { const char* e = getenv("TST_BF16_LN_FUSE"); return e != nullptr ? (int64_t)atoll(e) : 0; }();
+    return v;
+}
+
 bool tst_tfm_chain() {
     static const bool v = [] { const char* e = getenv("TST_TFM_CHAIN"); return e != nullptr && e[0] == '1'; }();
     return v;
@@ -121,7 +128,24 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
                                       nullptr, 0, nullptr, 0, nullptr, 0, 0, m->ht, m->ld_ht, R, d, stream));
             }
         }
-        for (int li = 0; !chain && li < m->n_layers; ++li) {
+        bool ln_fuse = c.bf16 && tst_bf16_ln_fuse_rows() > 0 && R >= tst_bf16_ln_fuse_rows() && tst_gemm_res_ln_ok(R, d, d) &&
+                       tst_gemm_res_ln_ok(R, d, m->d_ff);
+        for (int li = 0; ln_fuse && li < m->n_layers; ++li) ln_fuse = m->layers[li].cwq == nullptr;
+        for (int li = 0; ln_fuse && li < m->n_layers; ++li) {
+            // h always holds LayerNorm(x) for the next product: written by the previous residual product, or (layer 0) by a launch
+            const tst_tfm_layer& L = m->layers[li];
+            TST_REQUIRE(L.cache && L.wqkv && L.wo && L.w1 && L.w2, TST_ERR_ARG, "tst_tfm_step_run: layer %d incomplete", li);
+            char* slab = (char*)L.cache + t * m->slab_rows * 3 * d * esz;
+            if (li == 0) TST_TRY(c.layernorm(m->x, L.ln_self_g, L.ln_self_b, m->h));
+            TST_TRY(c.gemm(m->h, d, L.wqkv, L.ld_wqkv, L.bqkv, nullptr, 0, slab, 3 * d, 3 * d, d, 0, true));
+            TST_TRY(tst_attn_self_step_bf16(L.cache, m->slab_rows, anc, m->anc_ld, t, m->a, R, d, m->heads, stream));
+            TST_TRY(tst_gemm_res_ln_bf16(m->a, d, L.wo, L.ld_wo, L.bo, m->x, L.ln_ff_g, L.ln_ff_b, m->eps, m->h, d, R, d, d, stream));
+            TST_TRY(c.gemm(m->h, d, L.w1, L.ld_w1, L.b1, nullptr, 0, m->ff, m->d_ff, m->d_ff, d, 1, true));
+            const bool last = li + 1 == m->n_layers;
+            TST_TRY(tst_gemm_res_ln_bf16(m->ff, m->d_ff, L.w2, L.ld_w2, L.b2, m->x, last ? m->ln_g : m->layers[li + 1].ln_self_g,
+                                         last ? m->ln_b : m->layers[li + 1].ln_self_b, m->eps, m->h, d, R, d, m->d_ff, stream));
+        }
+        for (int li = 0; !chain && !ln_fuse && li < m->n_layers; ++li) {
             const tst_tfm_layer& L = m->layers[li];
             TST_REQUIRE(L.cache && L.wqkv && L.wo && L.w1 && L.w2, TST_ERR_ARG, "tst_tfm_step_run: layer %d incomplete", li);
             char* slab = (char*)L.cache + t * m->slab_rows * 3 * d * esz;   // the rows of position t
@@ -152,7 +176,7 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
             TST_TRY(c.ln_gemm(L.ln_ff_g, L.ln_ff_b, L.w1, L.ld_w1, L.b1, m->ff, m->d_ff, m->d_ff, 1));
             TST_TRY(c.gemm(m->ff, m->d_ff, L.w2, L.ld_w2, L.b2, m->x, d, m->x, d, d, m->d_ff, 0, false));
         }
-        if (chain) {}   // the last chain wrote the final LayerNorm k-major
+        if (chain || ln_fuse) {}   // the last chain wrote the final LayerNorm k-major / the last residual product wrote it into h
         else if (dma_vocab) TST_TRY(tst_layernorm_t_f32(m->x, m->ln_g, m->ln_b, m->eps, m->ht, m->ld_ht, R, d, stream));
         else TST_TRY(c.layernorm(m->x, m->ln_g, m->ln_b, m->h));
     }

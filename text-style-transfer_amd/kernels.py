@@ -146,6 +146,18 @@ def gemm_bf16(a, w, bias, out, n_rows, n_cols=None, res=None, act=0):
          _p(out), out.stride(0), n_rows, N, K, int(act), int(out.dtype == torch.bfloat16), _stream())
 
 
+def gemm_res_ln_bf16(a, w, bias, x, gamma, beta, h, n_rows, eps=1e-5):
+    """x[:n_rows] += a[:n_rows] @ w.T + bias (fp32 residual stream, 512 wide); h[:n_rows] = LayerNorm(x) in bf16: one kernel"""
+    for t, nm, dt in ((a, 'a', torch.bfloat16), (w, 'w', torch.bfloat16), (h, 'h', torch.bfloat16), (bias, 'bias', torch.float32)):
+        if t is not None and not (t.is_cuda and t.dtype == dt and t.stride(-1) == 1):
+            raise ValueError('%s must be a %s GPU tensor with unit inner stride' % (nm, dt))
+    _chk(x, torch.float32, 'x'); _chk(gamma, torch.float32, 'gamma'); _chk(beta, torch.float32, 'beta')
+    K, N = a.shape[1], w.shape[0]
+    assert w.shape[1] == K and x.shape[1] == N and h.shape[1] >= N and min(a.shape[0], x.shape[0], h.shape[0]) >= n_rows
+    call('tst_gemm_res_ln_bf16', _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(x), _p(gamma), _p(beta), float(eps), _p(h),
+         h.stride(0), n_rows, N, K, _stream())
+
+
 def gemm(a, wt, bias, out, n_rows, n_cols=None, res=None, act=0, strip=None):
     """out[:n_rows, :N] = epilogue(a[:n_rows] @ wt[:, :N] + bias); ``wt`` is [K, ldw] with ldw >= N.
     ``a``, ``out`` and ``res`` may be row-strided 2-D views (unit stride in the last dimension)."""
