@@ -44,7 +44,7 @@ OUT_SCALE = 2.0
 FP32_MATRIX_PEAK_TFLOPS = 157.3  # dense fp32 MFMA peak of MI355X
 BF16_MATRIX_PEAK_TFLOPS = 2500.0
 HBM_PEAK_GBS = 8000.0            # HBM3E peak of MI355X
-TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r02_vocab_gemm_traffic.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+TRAFFIC_FILE = os.path.join(ROOT, 'profiles', 'r03_vocab_gemm_traffic.json')   # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
 PEAKS_BIN = os.path.join(ROOT, 'tools', 'peaks')
 
 
