@@ -1,5 +1,5 @@
 #!/bin/bash
-# r03_a: do the round-3 host-side changes hold on the GPU?  (packed-encoder version check, lagged loop sync, no-alloc free-memory
+# r03_a: do the host-side changes hold on the GPU?  (packed-encoder version check, lagged loop sync, no-alloc free-memory
 # assertion, sharded bench fields + oracle sample, config 3 V=32000 full-size parity) + baseline lines for config 2 and config 4
 set -o pipefail
 mkdir -p gpurun_out/r03a

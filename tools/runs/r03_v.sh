@@ -1,5 +1,5 @@
 #!/bin/bash
-# r03_v: final third-round records: GPU suite, smoke, default bench line, rocprofv3 profile set of the bench command, config 1 / 3 / 4 lines
+# r03_v: final records of this series: GPU suite, smoke, default bench line, rocprofv3 profile set of the bench command, config 1 / 3 / 4 lines
 set -o pipefail
 mkdir -p gpurun_out
 timeout -k 10 900 python -u -m pytest tests -m gpu -x -q --timeout 180 --timeout-method thread > gpurun_out/r03_v_tests.log 2>&1 || { tail -30 gpurun_out/r03_v_tests.log; exit 1; }
