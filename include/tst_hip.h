@@ -37,7 +37,8 @@ extern "C" {
  * tst_select_step.n_sent_dev, tst_pack_sources, tst_scatter_rows_f32;
  * 105 = 104 + tst_vocab_stats_ok, tst_vocabproj_stats_bf16, tst_topk_from_stats_bf16, tst_tfm_step.part / n_slices,
  * tst_select_step.part / n_slices / stats_k, tst_gru_cell_fused_t_f32, tst_gru_step.ht / ld_ht;
- * 106 = 105 + tst_chain_ok, tst_chain_f32, tst_gemm_res_ln_ok, tst_gemm_res_ln_bf16 (additions only). */
+ * 106 = 105 + tst_chain_ok, tst_chain_f32, tst_gemm_res_ln_ok, tst_gemm_res_ln_bf16,
+ * tst_embed_posadd_rows_f32 (additions only). */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
@@ -47,6 +48,11 @@ const char* tst_last_error(void);
  * called from /root/reference/src/inference.py:132.  d % 4 == 0. */
 int tst_embed_posadd_f32(const int32_t* tok, const float* emb, const float* pe, const int32_t* pos, float scale, float* x,
                          int64_t R, int64_t d, int64_t V, void* stream);
+
+/* The same followed by x[r][:] += z[zidx[r]][:] (tst_add_rows_f32) in ONE pass over x: the embedding of a z-conditioned
+ * language model, lm(z, x) (/root/reference/src/trainers/lm_trainer.py:72-74).  Same additions in the same order. */
+int tst_embed_posadd_rows_f32(const int32_t* tok, const float* emb, const float* pe, const int32_t* pos, float scale,
+                              const float* z, const int32_t* zidx, float* x, int64_t R, int64_t d, int64_t V, void* stream);
 
 /* x[r][:] = x[r][:] * scale + pe[:]   (pe NULL: no add), in place.  The tail of an embedding that was computed
  * as a product, token distributions [R][V] times the embedding matrix [V][d] (tst_gemm_mfma_f32), which is

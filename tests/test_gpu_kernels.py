@@ -127,6 +127,15 @@ def test_embed_posadd_bit_exact(K):
     assert np.array_equal(out.cpu().numpy(), want)
     K.embed_posadd(dev(tok), dev(emb), None, 1.0, out, 33)
     assert np.array_equal(out.cpu().numpy(), emb[tok])
+    # with the conditioning vector of each row's sentence added in the same pass: == embedding, then the row add
+    z = r.standard_normal((7, 64)).astype(np.float32)
+    zidx = r.randint(0, 7, size=33).astype(np.int32)
+    K.embed_posadd_rows(dev(tok), dev(emb), dev(pe[3]), 8.0, dev(z), dev(zidx), out, 33)
+    assert np.array_equal(out.cpu().numpy(), C.embed_posadd(tok, emb, pe[3], 8.0) + z[zidx])
+    ref = torch.empty((33, 64), dtype=torch.float32, device='cuda')
+    K.embed_posadd(dev(tok), dev(emb), dev(pe[3]), 8.0, ref, 33)
+    K.add_rows(ref, dev(z), dev(zidx), 33)
+    assert torch.equal(out, ref)
 
 
 @pytest.mark.parametrize('d,heads,pos', [(256, 2, 0), (256, 2, 7), (256, 2, 49), (512, 8, 20), (64, 2, 5), (96, 1, 70),

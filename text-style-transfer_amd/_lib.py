@@ -79,6 +79,7 @@ _PROTOS = {
     'tst_version': ([], c_int),
     'tst_last_error': ([], ctypes.c_char_p),
     'tst_embed_posadd_f32': ([c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
+    'tst_embed_posadd_rows_f32': ([c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_scale_posadd_f32': ([c_vp, c_f32, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_layernorm_f32': ([c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_gemm_mfma_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp], c_int),

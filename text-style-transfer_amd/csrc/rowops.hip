@@ -7,7 +7,8 @@ namespace {
 // one thread per float4 of the output
 __global__ __launch_bounds__(256) void embed_posadd_kernel(const int32_t* __restrict__ tok, const float* __restrict__ emb,
                                                            const float* __restrict__ pe, const int32_t* __restrict__ pos,
-                                                           float scale, float* __restrict__ x, int64_t R, int d4, int64_t V) {
+                                                           float scale, float* __restrict__ x, int64_t R, int d4, int64_t V,
+                                                           const float* __restrict__ z = nullptr, const int32_t* __restrict__ zidx = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= R * d4) return;
     const int64_t r = i / d4;
@@ -20,6 +21,10 @@ __global__ __launch_bounds__(256) void embed_posadd_kernel(const int32_t* __rest
     if (pe != nullptr) {
         const float4 p = reinterpret_cast<const float4*>(pe)[(pos != nullptr ? (int64_t)pos[r] * d4 : 0) + c4];
         o.x = o.x + p.x; o.y = o.y + p.y; o.z = o.z + p.z; o.w = o.w + p.w;
+    }
+    if (z != nullptr) {   // + z[zidx[r]]: the add_rows_kernel step, in the same order
+        const float4 a = reinterpret_cast<const float4*>(z)[(int64_t)zidx[r] * d4 + c4];
+        o.x = o.x + a.x; o.y = o.y + a.y; o.z = o.z + a.z; o.w = o.w + a.w;
     }
     reinterpret_cast<float4*>(x)[i] = o;
 }
@@ -277,6 +282,18 @@ extern "C" int tst_embed_posadd_f32(const int32_t* tok, const float* emb, const 
     hipLaunchKernelGGL(embed_posadd_kernel, dim3(blocks_for(R * (d / 4), 256)), dim3(256), 0, (hipStream_t)stream, tok, emb,
                        pe, pos, scale, x, R, (int)(d / 4), V);
     return tst_after_launch("tst_embed_posadd_f32");
+}
+
+extern "C" int tst_embed_posadd_rows_f32(const int32_t* tok, const float* emb, const float* pe, const int32_t* pos, float scale,
+                                         const float* z, const int32_t* zidx, float* x, int64_t R, int64_t d, int64_t V, void* stream) {
+    TST_REQUIRE(tok && emb && x && (pe || !pos) && z && zidx, TST_ERR_ARG, "tst_embed_posadd_rows_f32: null pointer");
+    TST_REQUIRE(R >= 0 && d > 0 && d % 4 == 0 && V > 0, TST_ERR_ARG, "tst_embed_posadd_rows_f32: need d %% 4 == 0, V > 0");
+    TST_REQUIRE(tst_aligned16(emb) && tst_aligned16(x) && tst_aligned16(pe) && tst_aligned16(z), TST_ERR_ARG, "tst_embed_posadd_rows_f32: alignment");
+    TST_REQUIRE(R * (d / 4) < (1ll << 31) * 256, TST_ERR_UNSUPPORTED, "tst_embed_posadd_rows_f32: too large");
+    if (R == 0) return TST_OK;
+    hipLaunchKernelGGL(embed_posadd_kernel, dim3(blocks_for(R * (d / 4), 256)), dim3(256), 0, (hipStream_t)stream, tok, emb, pe, pos, scale,
+                       x, R, (int)(d / 4), V, z, zidx);
+    return tst_after_launch("tst_embed_posadd_rows_f32");
 }
 
 extern "C" int tst_scale_posadd_f32(float* x, float scale, const float* pe, int64_t R, int64_t d, void* stream) {

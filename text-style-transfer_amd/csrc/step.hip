@@ -85,10 +85,11 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
 
     if (phases & TST_STEP_EMBED) {
         TST_REQUIRE(tok && m->emb && m->pe, TST_ERR_ARG, "tst_tfm_step_run: null embedding input");
-        TST_TRY(tst_embed_posadd_f32(tok, m->emb, m->pe + t * d, nullptr, m->scale, m->x, R, d, m->V, stream));
-        if (m->z != nullptr) {
+        if (m->z != nullptr) {   // embedding, positional row and the sentence's conditioning vector in one pass
             TST_REQUIRE(sent != nullptr, TST_ERR_ARG, "tst_tfm_step_run: z without sent");
-            TST_TRY(tst_add_rows_f32(m->x, m->z, sent, R, d, stream));
+            TST_TRY(tst_embed_posadd_rows_f32(tok, m->emb, m->pe + t * d, nullptr, m->scale, m->z, sent, m->x, R, d, m->V, stream));
+        } else {
+            TST_TRY(tst_embed_posadd_f32(tok, m->emb, m->pe + t * d, nullptr, m->scale, m->x, R, d, m->V, stream));
         }
     }
     if (phases & TST_STEP_LAYERS) {

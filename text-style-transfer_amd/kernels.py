@@ -44,6 +44,15 @@ def embed_posadd(tok, emb, pe, scale, out, n_rows, pos=None):
     call('tst_embed_posadd_f32', _p(tok), _p(emb), _p(pe), _p(pos), float(scale), _p(out), n_rows, d, V, _stream())
 
 
+def embed_posadd_rows(tok, emb, pe, scale, z, zidx, out, n_rows, pos=None):
+    """out[:n_rows] = emb[tok] * scale + pe + z[zidx]: ``embed_posadd`` and ``add_rows`` in one pass"""
+    _chk(tok, torch.int32, 'tok'); _chk(emb, torch.float32, 'emb'); _chk(pe, torch.float32, 'pe'); _chk(z, torch.float32, 'z')
+    _chk(out, torch.float32, 'out'); _chk(pos, torch.int32, 'pos'); _chk(zidx, torch.int32, 'zidx')
+    V, d = emb.shape
+    assert out.shape[1] == d and z.shape[1] == d and min(out.shape[0], tok.shape[0], zidx.shape[0]) >= n_rows
+    call('tst_embed_posadd_rows_f32', _p(tok), _p(emb), _p(pe), _p(pos), float(scale), _p(z), _p(zidx), _p(out), n_rows, d, V, _stream())
+
+
 def soft_embed(dist, emb_pad, scale, pe, out, n_rows):
     """out[:n_rows] = (dist[:n_rows] @ emb_pad) * scale + pe: the embedding of token distributions.  ``dist`` is
     [rows, Vp] with Vp = V rounded up to a multiple of 4 (zero columns beyond V), ``emb_pad`` [Vp, d] (zero rows beyond V)."""
