@@ -70,9 +70,27 @@ def build_model(device, eos_bias):
     return model, vocab
 
 
-def decode_batch(model, vocab, src, beam, alpha, select_log=None):
-    """One pass of the hot path: encoder, decode loop; returns device tensors and the loop (for counters)."""
+class _Counts:
+    """steps_done / rows_stepped of the parts of a batch that was decoded as concurrent sub-batches"""
+    def __init__(self, loops):
+        self.steps_done = max(lp.steps_done for lp in loops)
+        self.rows_stepped = sum(lp.rows_stepped for lp in loops)
+
+
+def decode_batch(model, vocab, src, beam, alpha, select_log=None, parts=1):
+    """One pass of the hot path: encoder, decode loop; returns device tensors and the loop (for counters).
+    parts > 1: the batch's sentences are dealt to that many sub-batches (src[p::parts]: the same length profile each), which are
+    decoded at the same time on streams of their own (tst_amd.run_on_streams) and put back in order."""
+    import torch
     import tst_amd
+    if parts > 1 and src.shape[0] >= 2 * parts:
+        outs = tst_amd.run_on_streams([(lambda p=p: decode_batch(model, vocab, src[p::parts].contiguous(), beam, alpha)) for p in range(parts)])
+        tok = torch.empty((src.shape[0], outs[0][0].shape[1]), dtype=outs[0][0].dtype, device=src.device)
+        lens = torch.empty(src.shape[0], dtype=outs[0][1].dtype, device=src.device)
+        for p, (t, n, _) in enumerate(outs):
+            tok[p::parts] = t
+            lens[p::parts] = n
+        return tok, lens, _Counts([o[2] for o in outs])
     encs, enc_mask = model.encoder(src)
     st = tst_amd.InferenceState({'model': model.decoder, 'inputs': encs, 'enc_mask': enc_mask, 'vocab': vocab,
                                  'max_len': MAX_LEN, 'beam_size': beam, 'length_penalty': alpha})
@@ -203,6 +221,8 @@ def main():
     ap.add_argument('--sentences', type=int, default=1000000, help='--config 5: sentences in the corpus')
     ap.add_argument('--batch', type=int, default=8192, help='sentences per GPU per on-GPU batch')
     ap.add_argument('--beam', type=int, default=4)
+    ap.add_argument('--sub-batches', type=int, default=1, help='decode every on-GPU batch as that many concurrent sub-batches on '
+                    'streams of their own (same sentences, same outputs)')
     ap.add_argument('--alpha', type=float, default=0.0)
     ap.add_argument('--eos-bias', type=float, default=5.5)
     ap.add_argument('--cpu-sample', type=int, default=256)
@@ -272,7 +292,7 @@ def main():
     counters = {'rows': 0, 'loop_steps': 0, 'batches': 0, 'gather_s': 0.0}
 
     def decode_fn(batch):
-        tok, lens, loop = decode_batch(model, vocab, batch, args.beam, args.alpha)
+        tok, lens, loop = decode_batch(model, vocab, batch, args.beam, args.alpha, parts=args.sub_batches)
         counters['rows'] += loop.rows_stepped
         counters['loop_steps'] += loop.steps_done
         counters['batches'] += 1
@@ -356,7 +376,8 @@ def main():
             'ms_per_step': dt / args.steps * 1e3, 'higher_is_better': True, 'scaling': 'strong' if args.config == 5 else 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': workload, 'baseline_config': args.config, 'sentences_per_step': n_total,
-                       'sentences_per_gpu_batch': args.batch, 'beam': args.beam, 'max_len': MAX_LEN, 'vocab': VOCAB,
+                       'sentences_per_gpu_batch': args.batch, 'sub_batches': args.sub_batches, 'beam': args.beam, 'max_len': MAX_LEN,
+                       'vocab': VOCAB,
                        'eos_bias': args.eos_bias, 'mean_emitted_len': emitted / (args.steps * n_total),
                        'mean_emitted_len_note': 'eos_bias 5.5 gives ~23 tokens per sentence (~15 was the planning figure); longer '
                                                 'sentences mean more decode steps per batch, not fewer',

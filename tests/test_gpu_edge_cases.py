@@ -209,3 +209,36 @@ def test_concurrent_batches_on_streams_of_their_own_equal_sequential_decodes(T, 
     torch.cuda.synchronize()
     assert not errors, errors
     assert got == want
+
+
+def test_run_on_streams_returns_results_in_order_and_reraises(T):
+    """``tst_amd.run_on_streams``: parts of one batch decoded at the same time equal the whole batch; a job's exception reaches
+    the caller; tensors made on the caller's stream before the call are complete inside the jobs."""
+    tmodel, model, vocab, _, _ = mt_case(T, 300, 4, 9, 2.0, 6)
+    r = np.random.RandomState(3)
+    B, S = 96, 9
+    lens = r.randint(1, S + 1, size=B)
+    encs = r.standard_normal((B, S, 256)).astype(np.float32)
+    mask = (np.arange(S)[None] < lens[:, None])[:, None, :]
+    whole = decode(T, model, vocab, encs, mask, 18, 4)[0]
+    scale = torch.full((1,), 1.0, device='cuda')
+    e_dev = torch.from_numpy(encs).cuda() * scale          # produced on the caller's stream just before the call
+    m_dev = torch.from_numpy(mask).cuda()
+
+    def part(p):
+        st = T.InferenceState({'model': model.decoder, 'inputs': e_dev[p::3].contiguous(), 'enc_mask': m_dev[p::3].contiguous(),
+                               'vocab': vocab, 'max_len': 18, 'beam_size': 4})
+        return [s.cpu().tolist() for s in st.inference()]
+
+    parts = T.run_on_streams([(lambda p=p: part(p)) for p in range(3)])
+    merged = [None] * B
+    for p in range(3):
+        merged[p::3] = parts[p]
+    assert merged == whole
+
+    def boom():
+        raise ValueError('from a job')
+
+    with pytest.raises(ValueError, match='from a job'):
+        T.run_on_streams([lambda: 1, boom])
+    assert T.run_on_streams([lambda: 7]) == [7] and T.run_on_streams([]) == []

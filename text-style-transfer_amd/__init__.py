@@ -13,7 +13,8 @@ from .encoder import TransformerEncoder
 from .rnn import CharLMFromEmbs, ConditionalLM, FFN, Generator, RNNDecoder, RNNEncoder, RNNLM, WeightedLMEnsemble
 from .lm import TransformerLM
 from .postprocess import itos_many, compute_bleu_for_sents, corpus_bleu
+from .streams import run_on_streams
 
 __all__ = ['InferenceState', 'simple_inference', 'Vocab', 'HP', 'Transformer', 'TransformerDecoder', 'TransformerEncoder',
            'RNNDecoder', 'RNNEncoder', 'Generator', 'FFN', 'RNNLM', 'ConditionalLM', 'WeightedLMEnsemble', 'CharLMFromEmbs',
-           'TransformerLM', 'itos_many', 'compute_bleu_for_sents', 'corpus_bleu', 'TstError', 'version']
+           'TransformerLM', 'itos_many', 'compute_bleu_for_sents', 'corpus_bleu', 'run_on_streams', 'TstError', 'version']
