@@ -38,7 +38,9 @@ extern "C" {
  * 105 = 104 + tst_vocab_stats_ok, tst_vocabproj_stats_bf16, tst_topk_from_stats_bf16, tst_tfm_step.part / n_slices,
  * tst_select_step.part / n_slices / stats_k, tst_gru_cell_fused_t_f32, tst_gru_step.ht / ld_ht;
  * 106 = 105 + tst_chain_ok, tst_chain_f32, tst_gemm_res_ln_ok, tst_gemm_res_ln_bf16,
- * tst_embed_posadd_rows_f32 (additions only). */
+ * tst_embed_posadd_rows_f32 (additions only);
+ * 107 = 106 + tst_vocab_argmax_ok, tst_ln_vocab_argmax_f32, tst_tfm_step.argmax_keys, tst_select_step.am_keys /
+ * n_alive_host (the structs grew at their ends). */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
@@ -101,6 +103,23 @@ int tst_gemm_skinny_f32(const float* A, int64_t lda, const float* Wt, int64_t ld
  * receives the normalised rows.  x is [M][K] contiguous. */
 int tst_ln_gemm_f32(const float* x, const float* gamma, const float* beta, float eps, float* h, const float* Wt, int64_t ldw,
                     const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act, void* stream);
+
+/* Greedy decoding of a small batch: keys[m][s] = max of key(logit[m][n], n) over some of the columns n (every column counts
+ * for exactly one slot s of its row), with
+ *     logit[m][n] = bias[n] + sum_k LayerNorm(x)[m][k] * Wt[k][n]
+ * i.e. tst_layernorm_f32, tst_gemm_mfma_f32 and tst_argmax_rows_f32 as ONE kernel that stores neither the normalised rows
+ * nor the logits (torch.argmax of the model output at /root/reference/src/inference.py:132-145 under sampling_type "max").
+ * key(v, n) = (order-preserving bits of v, -0 read as +0) << 32 | ~n, raised with 64-bit atomic max operations, so keys
+ * [R][TST_ARGMAX_SLOTS] MUST BE ZERO ON ENTRY.  With key = the largest of a row's TST_ARGMAX_SLOTS keys (unsigned), the
+ * selected token of the row is (key == 0) ? 0 : ~(uint32_t)key: the first largest logit, NaN and -inf never selected, token 0
+ * for a row without any other value: exactly what tst_argmax_rows_f32 returns on the logits of the two separate calls (same
+ * fma chains, same LayerNorm order).  x is [R][d] contiguous, d = 256 or 512; tst_vocab_argmax_ok tells whether a shape is
+ * accepted (products small enough for 64 x 64 tiles: ceil(R / 128) * ceil(V / 128) < 640).
+ * ldw % 4 == 0, ldw >= V; 16-byte aligned x, gamma, beta, Wt; bias may be NULL. */
+#define TST_ARGMAX_SLOTS 16
+int tst_vocab_argmax_ok(int64_t R, int64_t V, int64_t d);
+int tst_ln_vocab_argmax_f32(const float* x, const float* gamma, const float* beta, float eps, const float* Wt, int64_t ldw,
+                            const float* bias, uint64_t* keys, int64_t R, int64_t V, int64_t d, void* stream);
 
 /* A residual product, the LayerNorm behind it and the product behind that as ONE kernel per tile of 64 whole rows
  * (d_model = 256):
@@ -421,6 +440,11 @@ typedef struct tst_tfm_step {
                                tst_vocab_stats_ok(rows, V, d), the vocabulary projection is tst_vocabproj_stats_bf16 and
                                tst_select_step_run (given the same buffer) reads them instead of the whole rows.  Same logits. */
     int64_t n_slices;       /* ceil(V / 64) */
+    uint64_t* argmax_keys;  /* fp32 only, optional (the caller may change it between calls): [slab_rows][TST_ARGMAX_SLOTS].  When set, a call with
+                               all three phases on a shape tst_vocab_argmax_ok(rows, V, d) accepts ends in
+                               tst_ln_vocab_argmax_f32 instead of the final LayerNorm and the vocabulary projection: the
+                               embedding kernel clears the keys of rows 0..rows-1, logits and h are NOT written.  Any other call with it
+                               set fails with TST_ERR_UNSUPPORTED. */
 } tst_tfm_step;
 #define TST_DMA_MIN_ROWS 2048
 
@@ -491,6 +515,11 @@ typedef struct tst_select_step {
                                     tst_topk_from_stats_bf16 instead of tst_logsoftmax_topk_bf16 */
     int64_t n_slices;            /* ceil(V / 64) */
     int64_t stats_k;             /* inner dimension of the vocabulary projection that wrote `part` (d_model) */
+    const uint64_t* am_keys;     /* NULL, or (k == 1, sample == 0) the keys tst_tfm_step_run left in tst_tfm_step.argmax_keys: the
+                                    tokens are decoded from them, logits are not read and am is not written */
+    int32_t* n_alive_host;       /* NULL, or a device-visible address of page-locked HOST memory that receives the same count as
+                                    n_alive, stored by the kernel that computes it (a caller that reads the count one step late
+                                    saves the device-to-host copy it would otherwise queue behind every step) */
 } tst_select_step;
 
 int tst_select_step_run(const tst_select_step* s, const tst_rows* cur, const tst_rows* nxt, int64_t n_sent, int64_t k_in,

@@ -45,7 +45,8 @@ class TstTfmStep(ctypes.Structure):
                 ('z', c_vp), ('mask', c_vp), ('kvrow', c_vp), ('ln_g', c_vp), ('ln_b', c_vp),
                 ('wout', c_vp), ('bout', c_vp), ('ld_wout', c_i64),
                 ('x', c_vp), ('h', c_vp), ('q', c_vp), ('a', c_vp), ('ff', c_vp), ('logits', c_vp), ('ld_logits', c_i64),
-                ('layers', ctypes.POINTER(TstTfmLayer)), ('ht', c_vp), ('ld_ht', c_i64), ('part', c_vp), ('n_slices', c_i64)]
+                ('layers', ctypes.POINTER(TstTfmLayer)), ('ht', c_vp), ('ld_ht', c_i64), ('part', c_vp), ('n_slices', c_i64),
+                ('argmax_keys', c_vp)]
 
 
 class TstGruLayer(ctypes.Structure):
@@ -70,7 +71,8 @@ class TstSelectStep(ctypes.Structure):
                 ('lp', c_vp), ('T', c_i64), ('top_ends', c_i32), ('sample', c_i32), ('temperature', c_f32),
                 ('seed', ctypes.c_uint32),
                 ('out_tok', c_vp), ('out_len', c_vp), ('out_score', c_vp), ('scratch_alive_pos', c_vp), ('row_parent', c_vp),
-                ('n_alive', c_vp), ('n_sent_dev', c_vp), ('part', c_vp), ('n_slices', c_i64), ('stats_k', c_i64)]
+                ('n_alive', c_vp), ('n_sent_dev', c_vp), ('part', c_vp), ('n_slices', c_i64), ('stats_k', c_i64),
+                ('am_keys', c_vp), ('n_alive_host', c_vp)]
 
 
 STEP_EMBED, STEP_LAYERS, STEP_VOCAB, STEP_FUSED_CELL = 1, 2, 4, 8
@@ -87,6 +89,8 @@ _PROTOS = {
     'tst_layernorm_t_f32': ([c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_gemm_skinny_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_int, c_vp], c_int),
     'tst_ln_gemm_f32': ([c_vp, c_vp, c_vp, c_f32, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_int, c_vp], c_int),
+    'tst_vocab_argmax_ok': ([c_i64, c_i64, c_i64], c_int),
+    'tst_ln_vocab_argmax_f32': ([c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_chain_ok': ([c_i64, c_i64, c_i64, c_i64], c_int),
     'tst_chain_f32': ([c_vp, c_i64, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_f32, c_vp, c_i64, c_vp, c_int, c_vp, c_i64, c_i64, c_vp, c_i64,
                        c_i64, c_i64, c_vp], c_int),

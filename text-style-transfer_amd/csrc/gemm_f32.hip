@@ -10,6 +10,8 @@
 // multiplied (three LDS buffers, one barrier per tile, taken in the middle of the tile's MFMAs).  Workgroups are renumbered so that each XCD
 // walks a contiguous, m-grouped range of tiles and re-reads A / Wt panels from its own L2.
 #include "tst_common.h"
+#include <limits.h>
+#include <math.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -675,6 +677,213 @@ void launch_skinny_ln(const float* X, int64_t ldx, const float* gamma, const flo
 #undef TST_SKLN_LAUNCH
 }
 
+// ---- greedy decoding of small batches: final LayerNorm, vocabulary projection and arg-max in one kernel -------------------
+// keys[m][slot] = max of key(logit[m][n], n) over the columns n of the tiles that use the slot, logit = bias[n] + sum_k
+// LayerNorm(x)[m][k] * Wt[k][n]: neither the normalised rows nor the logits travel through memory.  Tiles of 64 x 64 x 32 with
+// k-major LDS images in three buffers and one barrier per k-tile, as gemm_f32_k32_kernel, with these differences:
+//  - every wave loads 16 of the tile's rows COMPLETELY into registers (lane (r, kq) holds the float4 chunks 4 c + kq of row r, as
+//    gemm_f32_skinny_ln_kernel), computes their LayerNorm statistics in exactly the order of layernorm_kernel (64 interleaved
+//    partial sums folded in the butterfly's order) and normalises them in place: the A tiles of the k loop are written to LDS
+//    from these registers, so x is read once per workgroup and the k loop loads only Wt;
+//  - the product is computed transposed (operands swapped: the same fma chain per element), so that a lane owns a ROW and
+//    its 16 accumulator registers are 16 columns of it, ascending;
+//  - the epilogue keeps the first largest logit of the lane's columns (v > best, as argmax_rows_kernel), merges the two halves
+//    of the wave and, through LDS, the two waves that share the rows, and raises keys[row][tile column % TST_ARGMAX_SLOTS] with
+//    one 64-bit atomic max per row and workgroup.  The slots spread the atomics of a row over 16 addresses.
+// key = order-preserving bits of the value (with -0 read as +0) in the upper word, ~column in the lower: the largest key is the
+// largest value at its smallest column.  NaN and -inf never form a key, so a row without any finite or +inf logit keeps key 0,
+// which decodes to token 0, as tst_argmax_rows_f32 gives.  keys must be 0 on entry.
+__device__ __forceinline__ unsigned long long argmax_key(float v, int col) {
+    if (v == 0.0f) v = 0.0f;   // -0 -> +0: the two compare equal in argmax_rows_kernel
+    uint32_t u = __float_as_uint(v);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (uint32_t)(~(uint32_t)col);
+}
+
+template <int KCH>
+__global__ __launch_bounds__(256, (KCH <= 16 ? 3 : 2)) void ln_vocab_argmax_kernel(const float* __restrict__ X, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float eps, const float* __restrict__ W,
+                                                                 int64_t ldw, const float* __restrict__ bias, unsigned long long* keys,
+                                                                 int M, int N, int tiles_m, int tiles_n) {
+    constexpr int K = 16 * KCH, BM = 64, BN = 64, KT = 32, LDA = 66, LDB = 68, NKT = K / KT;
+    __shared__ __attribute__((aligned(16))) float As[3][KT][LDA];
+    __shared__ __attribute__((aligned(16))) float Bs[3][KT][LDB];
+    __shared__ unsigned long long key_s[BM];
+
+    const int nwg = tiles_m * tiles_n;
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, q = nwg >> 3, rem = nwg & 7;
+    const int lb = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + (bid >> 3);
+    const int per_group = GROUP_M * tiles_n;
+    const int first_m = (lb / per_group) * GROUP_M;
+    const int gsz = min(tiles_m - first_m, GROUP_M);
+    const int tm = first_m + (lb % per_group) % gsz;
+    const int tn = (lb % per_group) / gsz;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // Wt tile: 16 bytes at n = 4 (t & 15) of k-rows (t >> 4), + 16; the first two tiles are requested before anything else
+    const int bnq = (t & 15) * 4, bk = t >> 4;
+    const float* w_p0 = W + (int64_t)bk * ldw + min(n0 + bnq, (int)ldw - 4);
+    const float* w_p1 = w_p0 + 16 * ldw;
+    float4 rb0 = *reinterpret_cast<const float4*>(w_p0);
+    float4 rb1 = *reinterpret_cast<const float4*>(w_p1);
+    const int kq0 = lane >> 4;
+    const float4 gf0 = *reinterpret_cast<const float4*>(gamma + 4 * kq0), gf1 = *reinterpret_cast<const float4*>(gamma + 16 + 4 * kq0);
+    const float4 tf0 = *reinterpret_cast<const float4*>(beta + 4 * kq0), tf1 = *reinterpret_cast<const float4*>(beta + 16 + 4 * kq0);
+
+    // rows m0 + 16 wave + r of x: lane (r, kq) holds the chunks 4 c + kq (elements 16 c + 4 kq .. + 3) of its row
+    const int r = lane & 15, kq = lane >> 4;
+    const int srow = 16 * wave + r;
+    float4 a[KCH];
+    float mean, rstd;
+    {
+        const float* x_row = X + (int64_t)min(m0 + srow, M - 1) * K;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) a[c] = *reinterpret_cast<const float4*>(x_row + 16 * c + 4 * kq);
+        auto row_total = [&](float (&p)[16]) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) p[c] = p[c] + p[c + 8];      // butterfly level 32
+#pragma unroll
+            for (int c = 0; c < 4; ++c) p[c] = p[c] + p[c + 4];      // 16
+#pragma unroll
+            for (int c = 0; c < 2; ++c) p[c] = p[c] + p[c + 2];      // 8
+            float v = p[0] + p[1];                                   // 4
+            v = v + lane_xor<32>(v);                                 // 2
+            v = v + lane_xor<16>(v);                                 // 1
+            return v;
+        };
+        float p[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float s = 0.0f;
+#pragma unroll
+            for (int c = j; c < KCH; c += 16) { s = s + a[c].x; s = s + a[c].y; s = s + a[c].z; s = s + a[c].w; }
+            p[j] = s;
+        }
+        const float dlen = (float)K;
+        mean = row_total(p) / dlen;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            float s = 0.0f;
+#pragma unroll
+            for (int c = j; c < KCH; c += 16) {
+                float u;
+                u = a[c].x - mean; s = __builtin_fmaf(u, u, s);
+                u = a[c].y - mean; s = __builtin_fmaf(u, u, s);
+                u = a[c].z - mean; s = __builtin_fmaf(u, u, s);
+                u = a[c].w - mean; s = __builtin_fmaf(u, u, s);
+            }
+            p[j] = s;
+        }
+        const float var = row_total(p) / dlen;
+        rstd = 1.0f / sqrtf(var + eps);
+    }
+    // k-tile kt of A is the chunks 2 kt and 2 kt + 1 of every row: k = 4 kq + i and 16 + 4 kq + i of the tile, normalised on
+    // their way into LDS with the tile's gamma / beta (requested a tile ahead, with the Wt tile)
+    float4 g0, g1, t0, t1;
+    auto store_a = [&](int buf, const float4& c0, const float4& c1) {
+        As[buf][4 * kq + 0][srow] = __builtin_fmaf((c0.x - mean) * rstd, g0.x, t0.x);
+        As[buf][4 * kq + 1][srow] = __builtin_fmaf((c0.y - mean) * rstd, g0.y, t0.y);
+        As[buf][4 * kq + 2][srow] = __builtin_fmaf((c0.z - mean) * rstd, g0.z, t0.z);
+        As[buf][4 * kq + 3][srow] = __builtin_fmaf((c0.w - mean) * rstd, g0.w, t0.w);
+        As[buf][16 + 4 * kq + 0][srow] = __builtin_fmaf((c1.x - mean) * rstd, g1.x, t1.x);
+        As[buf][16 + 4 * kq + 1][srow] = __builtin_fmaf((c1.y - mean) * rstd, g1.y, t1.y);
+        As[buf][16 + 4 * kq + 2][srow] = __builtin_fmaf((c1.z - mean) * rstd, g1.z, t1.z);
+        As[buf][16 + 4 * kq + 3][srow] = __builtin_fmaf((c1.w - mean) * rstd, g1.w, t1.w);
+    };
+    auto store_b = [&](int buf) {
+        *reinterpret_cast<float4*>(&Bs[buf][bk][bnq]) = rb0;
+        *reinterpret_cast<float4*>(&Bs[buf][bk + 16][bnq]) = rb1;
+    };
+    auto load_gb = [&](int k0) {
+        g0 = *reinterpret_cast<const float4*>(gamma + k0 + 4 * kq);
+        g1 = *reinterpret_cast<const float4*>(gamma + k0 + 16 + 4 * kq);
+        t0 = *reinterpret_cast<const float4*>(beta + k0 + 4 * kq);
+        t1 = *reinterpret_cast<const float4*>(beta + k0 + 16 + 4 * kq);
+    };
+    auto load_b = [&](int k0) {
+        rb0 = *reinterpret_cast<const float4*>(w_p0 + (int64_t)k0 * ldw);
+        rb1 = *reinterpret_cast<const float4*>(w_p1 + (int64_t)k0 * ldw);
+        load_gb(k0);
+    };
+
+    // lane owns row (lane & 31) of the wave's 32 x 32 block; register j is column (j & 3) + 8 (j >> 2) + 4 (lane >> 5)
+    const int cbase = n0 + wn * 32 + 4 * (lane >> 5);
+    f32x16 acc;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int col = cbase + (j & 3) + 8 * (j >> 2);
+        acc[j] = (bias != nullptr && col < N) ? bias[col] : 0.0f;
+    }
+
+    g0 = gf0; g1 = gf1; t0 = tf0; t1 = tf1;
+    store_a(0, a[0], a[1]);
+    store_b(0);
+    load_b(KT);
+    __syncthreads();
+    const int arow = wm * 32 + (lane & 31), bcol = wn * 32 + (lane & 31), khalf = lane >> 5;
+    float a_cur = As[0][khalf][arow], b_cur = Bs[0][khalf][bcol], a_nxt = 0.f, b_nxt = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NKT; ++kt) {
+        const int buf = kt % 3, nbuf = (kt + 1) % 3;
+#pragma unroll
+        for (int kk = 0; kk < KT; kk += 2) {
+            if (kk + 2 < KT) {
+                a_nxt = As[buf][kk + 2 + khalf][arow];
+                b_nxt = Bs[buf][kk + 2 + khalf][bcol];
+            } else if (kt + 1 < NKT) {
+                a_nxt = As[nbuf][khalf][arow];
+                b_nxt = Bs[nbuf][khalf][bcol];
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(b_cur, a_cur, acc, 0, 0, 0);
+            a_cur = a_nxt;
+            b_cur = b_nxt;
+            if (kk == KT / 2 - 2) {
+                if (kt + 1 < NKT) {
+                    store_a(nbuf, a[(2 * kt + 2) % KCH], a[(2 * kt + 3) % KCH]);
+                    store_b(nbuf);
+                    if (kt + 2 < NKT) load_b((kt + 2) * KT);
+                }
+                __syncthreads();
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);   // the loop is unrolled (a[] is indexed by kt): keep the tiles' instructions apart
+    }
+
+    float bv = -INFINITY;
+    int bi = INT_MAX;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int col = cbase + (j & 3) + 8 * (j >> 2);
+        if (col < N && acc[j] > bv) { bv = acc[j]; bi = col; }
+    }
+    {
+        const float ov = lane_xor<32>(bv);
+        const int oi = lane_xor_i<32>(bi);
+        if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+    }
+    // the two waves of a row block: the right one hands its keys over through LDS (its columns are the larger ones, so on
+    // equal values the left wave's key is the larger, as it must be)
+    unsigned long long key = bi != INT_MAX ? argmax_key(bv, bi) : 0ull;
+    if (wn == 1 && lane < 32) key_s[wm * 32 + lane] = key;
+    __syncthreads();
+    if (wn == 0 && lane < 32) {
+        const unsigned long long other = key_s[wm * 32 + lane];
+        if (other > key) key = other;
+        const int row = m0 + wm * 32 + lane;
+        if (row < M && key != 0ull) {
+            unsigned long long* kp = keys + (int64_t)row * TST_ARGMAX_SLOTS + (tn % TST_ARGMAX_SLOTS);
+            // unconditionally: reading the key first, to skip atomics that cannot win, made the kernel 6 - 12 us slower (a load
+            // round trip at the end of every workgroup) while the atomics themselves cost under 1 us (measured)
+            atomicMax(kp, key);
+        }
+    }
+}
+
 int check_gemm_args(const char* who, const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* res, int64_t ldr,
                     float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act) {
     TST_REQUIRE(A && Wt && C, TST_ERR_ARG, "%s: null pointer", who);
@@ -722,6 +931,32 @@ extern "C" int tst_ln_gemm_f32(const float* x, const float* gamma, const float* 
     const int rc2 = tst_layernorm_f32(x, gamma, beta, eps, h, M, K, stream);
     if (rc2 != TST_OK) return rc2;
     return tst_gemm_mfma_f32(h, K, Wt, ldw, bias, nullptr, 0, C, ldc, M, N, K, act, stream);
+}
+
+// shapes for which the fused kernel replaces LayerNorm + tst_gemm_mfma_f32 + tst_argmax_rows_f32: rows of 256 or 512 floats and
+// a product small enough that tst_gemm_mfma_f32 would itself run 64 x 64 tiles (or strips)
+extern "C" int tst_vocab_argmax_ok(int64_t R, int64_t V, int64_t d) {
+    return (d == 256 || d == 512) && R >= 1 && V >= 1 && V < (1ll << 30) && ((R + 127) / 128) * ((V + 127) / 128) < 640;
+}
+
+extern "C" int tst_ln_vocab_argmax_f32(const float* x, const float* gamma, const float* beta, float eps, const float* Wt, int64_t ldw,
+                                       const float* bias, uint64_t* keys, int64_t R, int64_t V, int64_t d, void* stream) {
+    TST_REQUIRE(x && gamma && beta && Wt && keys, TST_ERR_ARG, "tst_ln_vocab_argmax_f32: null pointer");   // keys: [R][TST_ARGMAX_SLOTS]
+    TST_REQUIRE(R >= 0 && V > 0 && ldw % 4 == 0 && ldw >= V && ldw >= 4, TST_ERR_ARG, "tst_ln_vocab_argmax_f32: bad sizes (ldw %% 4 == 0, ldw >= V)");
+    TST_REQUIRE(tst_aligned16(x) && tst_aligned16(gamma) && tst_aligned16(beta) && tst_aligned16(Wt) && tst_aligned16(keys),
+                TST_ERR_ARG, "tst_ln_vocab_argmax_f32: alignment");
+    if (R == 0) return TST_OK;
+    TST_REQUIRE(tst_vocab_argmax_ok(R, V, d), TST_ERR_UNSUPPORTED,
+                "tst_ln_vocab_argmax_f32: rows of 256 or 512 floats and ceil(R / 128) * ceil(V / 128) < 640 (see tst_vocab_argmax_ok)");
+    const int64_t tiles_m = (R + 63) / 64, tiles_n = (V + 63) / 64;
+    const dim3 grid((unsigned)(tiles_m * tiles_n));
+    if (d == 256)
+        hipLaunchKernelGGL((ln_vocab_argmax_kernel<16>), grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, Wt, ldw, bias,
+                           (unsigned long long*)keys, (int)R, (int)V, (int)tiles_m, (int)tiles_n);
+    else
+        hipLaunchKernelGGL((ln_vocab_argmax_kernel<32>), grid, dim3(256), 0, (hipStream_t)stream, x, gamma, beta, eps, Wt, ldw, bias,
+                           (unsigned long long*)keys, (int)R, (int)V, (int)tiles_m, (int)tiles_n);
+    return tst_after_launch("tst_ln_vocab_argmax_f32");
 }
 
 extern "C" int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias,

@@ -8,11 +8,13 @@ namespace {
 __global__ __launch_bounds__(256) void embed_posadd_kernel(const int32_t* __restrict__ tok, const float* __restrict__ emb,
                                                            const float* __restrict__ pe, const int32_t* __restrict__ pos,
                                                            float scale, float* __restrict__ x, int64_t R, int d4, int64_t V,
-                                                           const float* __restrict__ z = nullptr, const int32_t* __restrict__ zidx = nullptr) {
+                                                           const float* __restrict__ z = nullptr, const int32_t* __restrict__ zidx = nullptr,
+                                                           unsigned long long* __restrict__ clear_keys = nullptr) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= R * d4) return;
     const int64_t r = i / d4;
     const int c4 = (int)(i - r * d4);
+    if (clear_keys != nullptr && c4 < TST_ARGMAX_SLOTS) clear_keys[r * TST_ARGMAX_SLOTS + c4] = 0ull;   // the step's arg-max keys start at "no candidate"
     int64_t id = tok[r];
     id = id < 0 ? 0 : (id >= V ? V - 1 : id);
     float4 e = reinterpret_cast<const float4*>(emb + id * (int64_t)d4 * 4)[c4];
@@ -294,6 +296,20 @@ extern "C" int tst_embed_posadd_rows_f32(const int32_t* tok, const float* emb, c
     hipLaunchKernelGGL(embed_posadd_kernel, dim3(blocks_for(R * (d / 4), 256)), dim3(256), 0, (hipStream_t)stream, tok, emb, pe, pos, scale,
                        x, R, (int)(d / 4), V, z, zidx);
     return tst_after_launch("tst_embed_posadd_rows_f32");
+}
+
+int tst_embed_posadd_clear_f32(const int32_t* tok, const float* emb, const float* pe, float scale, const float* z, const int32_t* zidx,
+                               float* x, uint64_t* clear_keys, int64_t R, int64_t d, int64_t V, void* stream) {
+    TST_REQUIRE(tok && emb && x && (z == nullptr || zidx != nullptr), TST_ERR_ARG, "tst_embed_posadd_clear_f32: null pointer");
+    TST_REQUIRE(R >= 0 && d > 0 && d % 4 == 0 && V > 0 && (clear_keys == nullptr || d / 4 >= TST_ARGMAX_SLOTS), TST_ERR_ARG,
+                "tst_embed_posadd_clear_f32: need d %% 4 == 0, V > 0 (and d >= 4 * TST_ARGMAX_SLOTS to clear keys)");
+    TST_REQUIRE(tst_aligned16(emb) && tst_aligned16(x) && tst_aligned16(pe) && tst_aligned16(z) && ((uintptr_t)clear_keys & 7u) == 0, TST_ERR_ARG,
+                "tst_embed_posadd_clear_f32: alignment");
+    TST_REQUIRE(R * (d / 4) < (1ll << 31) * 256, TST_ERR_UNSUPPORTED, "tst_embed_posadd_clear_f32: too large");
+    if (R == 0) return TST_OK;
+    hipLaunchKernelGGL(embed_posadd_kernel, dim3(blocks_for(R * (d / 4), 256)), dim3(256), 0, (hipStream_t)stream, tok, emb, pe,
+                       (const int32_t*)nullptr, scale, x, R, (int)(d / 4), V, z, zidx, (unsigned long long*)clear_keys);
+    return tst_after_launch("tst_embed_posadd_clear_f32");
 }
 
 extern "C" int tst_scale_posadd_f32(float* x, float scale, const float* pe, int64_t R, int64_t d, void* stream) {

@@ -444,12 +444,26 @@ __global__ __launch_bounds__(512) void topk_from_stats_kernel(const __bf16* __re
     }
 }
 
-__global__ __launch_bounds__(256) void greedy_select_kernel(const int32_t* __restrict__ am, int64_t n, int32_t eos,
-                                                            int32_t* parent, int32_t* tok, float* score, int32_t* fin,
-                                                            int32_t* nemit, tst_rows cur) {
+// token of a row's arg-max keys (tst_ln_vocab_argmax_f32: TST_ARGMAX_SLOTS keys per row, 16-byte aligned): the largest key
+// decides; 0 = no candidate, else ~column in the lower word
+__device__ __forceinline__ int32_t key_token(const unsigned long long* __restrict__ row_keys) {
+    unsigned long long key = 0ull;
+#pragma unroll
+    for (int s = 0; s < TST_ARGMAX_SLOTS; s += 2) {
+        const ulonglong2 v = *reinterpret_cast<const ulonglong2*>(row_keys + s);
+        key = v.x > key ? v.x : key;
+        key = v.y > key ? v.y : key;
+    }
+    return key == 0ull ? 0 : (int32_t)~(uint32_t)key;
+}
+
+// am: the selected token of every row; keys (when not NULL): arg-max keys instead
+__global__ __launch_bounds__(256) void greedy_select_kernel(const int32_t* __restrict__ am, const unsigned long long* __restrict__ keys,
+                                                            int64_t n, int32_t eos, int32_t* parent, int32_t* tok, float* score,
+                                                            int32_t* fin, int32_t* nemit, tst_rows cur) {
     const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (r >= n) return;
-    const int32_t tk = am[r];
+    const int32_t tk = keys != nullptr ? key_token(keys + r * TST_ARGMAX_SLOTS) : am[r];
     parent[r] = (int32_t)r;
     tok[r] = tk;
     score[r] = 0.0f;
@@ -547,7 +561,7 @@ __global__ __launch_bounds__(256) void finish_kernel(tst_rows cur, const int32_t
 
 // exclusive prefix sum of alive[0..n) by one workgroup of 1024 threads; pos[a] = new sentence index
 __global__ __launch_bounds__(1024) void scan_alive_kernel(const int32_t* __restrict__ alive, int32_t* __restrict__ pos,
-                                                          int64_t n, int32_t* __restrict__ n_alive) {
+                                                          int64_t n, int32_t* __restrict__ n_alive, int32_t* n_alive_host) {
     __shared__ int wsum[16];
     const int t = threadIdx.x;
     const int64_t per = (n + 1023) / 1024;
@@ -567,7 +581,10 @@ __global__ __launch_bounds__(1024) void scan_alive_kernel(const int32_t* __restr
     for (int q = 0; q < (t >> 6); ++q) wbase += wsum[q];
     int run = wbase + inc - local;
     for (int64_t i = lo; i < hi; ++i) { pos[i] = run; run += alive[i]; }
-    if (t == 1023) *n_alive = wbase + inc;
+    if (t == 1023) {
+        *n_alive = wbase + inc;
+        if (n_alive_host != nullptr) *n_alive_host = wbase + inc;
+    }
 }
 
 // one wave per new row slot (a, j) of a surviving sentence
@@ -605,19 +622,20 @@ __global__ __launch_bounds__(256) void gather_state_kernel(tst_rows cur, tst_row
 // Small batches: greedy selection (optional), retirement, the prefix sum and the gather in ONE workgroup of 1024
 // threads (at most 1024 sentences and 1024 rows), the same arithmetic as the four kernels above, phase by phase.
 template <bool GREEDY>
-__global__ __launch_bounds__(1024) void tail_small_kernel(tst_rows cur, tst_rows nxt, const int32_t* __restrict__ am, int32_t* parent,
+__global__ __launch_bounds__(1024) void tail_small_kernel(tst_rows cur, tst_rows nxt, const int32_t* __restrict__ am,
+                                                          const unsigned long long* __restrict__ keys, int32_t* parent,
                                                           int32_t* tok, float* score, int32_t* fin, int32_t* nemit,
                                                           const float* __restrict__ lp, int n_sent, int k, int step, int T,
                                                           int32_t eos, int last_step, int top_ends, int32_t* out_tok,
                                                           int32_t* out_len, float* out_score, int32_t* row_parent,
-                                                          int32_t* n_alive, const int32_t* __restrict__ n_true) {
+                                                          int32_t* n_alive, const int32_t* __restrict__ n_true, int32_t* n_alive_host) {
     __shared__ int alive_s[1024], pos_s[1024], wsum[16];
     const int t = threadIdx.x;
     if (n_true != nullptr) n_sent = min(n_sent, (int)*n_true);   // n_sent may be an upper bound: see finish_kernel
     const int n_rows = n_sent * k;
     if (GREEDY) {   // greedy_select_kernel (k == 1)
         if (t < n_rows) {
-            const int32_t tk = am[t];
+            const int32_t tk = keys != nullptr ? key_token(keys + (int64_t)t * TST_ARGMAX_SLOTS) : am[t];
             parent[t] = t;
             tok[t] = tk;
             score[t] = 0.0f;
@@ -664,7 +682,10 @@ __global__ __launch_bounds__(1024) void tail_small_kernel(tst_rows cur, tst_rows
     for (int q = 0; q < (t >> 6); ++q) wbase += wsum[q];
     alive_s[t] = al;
     pos_s[t] = wbase + inc - al;
-    if (t == 1023) *n_alive = wbase + inc;
+    if (t == 1023) {
+        *n_alive = wbase + inc;
+        if (n_alive_host != nullptr) *n_alive_host = wbase + inc;
+    }
     __syncthreads();
     // gather_state_kernel: per-slot scalars by the slot's thread, then the history and ancestor rows element by element
     // over the whole workgroup (every load independent of the others)
@@ -843,7 +864,7 @@ extern "C" int tst_greedy_select(const int32_t* argmax_tok, int64_t n_rows, int3
     TST_REQUIRE(n_rows >= 0, TST_ERR_ARG, "tst_greedy_select: bad size");
     if (n_rows == 0) return TST_OK;
     hipLaunchKernelGGL(greedy_select_kernel, dim3(blocks_for(n_rows, 256)), dim3(256), 0, (hipStream_t)stream, argmax_tok,
-                       n_rows, eos, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, *cur);
+                       (const unsigned long long*)nullptr, n_rows, eos, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, *cur);
     return tst_after_launch("tst_greedy_select");
 }
 
@@ -866,7 +887,7 @@ int retire_compact_impl(const tst_rows* cur, const tst_rows* nxt, const int32_t*
                         const float* sel_score, const int32_t* sel_fin, const int32_t* sel_nemit, const float* lp, int64_t n_sent,
                         int64_t k, int64_t step, int64_t T, int32_t eos, int last_step, int top_ends, int32_t* out_tok,
                         int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent, int32_t* n_alive,
-                        void* stream, const char* name, const int32_t* n_true = nullptr) {
+                        void* stream, const char* name, const int32_t* n_true = nullptr, int32_t* n_alive_host = nullptr) {
     TST_REQUIRE(rows_ok(cur, false) && rows_ok(nxt, cur && cur->anc) && sel_parent && sel_tok && sel_score && sel_fin &&
                     sel_nemit && lp && out_tok && out_len && out_score && scratch_alive_pos && row_parent && n_alive,
                 TST_ERR_ARG, "%s: null pointer", name);
@@ -874,10 +895,11 @@ int retire_compact_impl(const tst_rows* cur, const tst_rows* nxt, const int32_t*
                 "%s: bad sizes (need 0 <= step < T, 1 <= k <= 8)", name);
     hipStream_t st = (hipStream_t)stream;
     if (n_sent * k <= SMALL_TAIL_ROWS) {   // one workgroup does all three steps
-        hipLaunchKernelGGL(tail_small_kernel<false>, dim3(1), dim3(1024), 0, st, *cur, *nxt, nullptr, const_cast<int32_t*>(sel_parent),
+        hipLaunchKernelGGL(tail_small_kernel<false>, dim3(1), dim3(1024), 0, st, *cur, *nxt, (const int32_t*)nullptr,
+                           (const unsigned long long*)nullptr, const_cast<int32_t*>(sel_parent),
                            const_cast<int32_t*>(sel_tok), const_cast<float*>(sel_score), const_cast<int32_t*>(sel_fin),
                            const_cast<int32_t*>(sel_nemit), lp, (int)n_sent, (int)k, (int)step, (int)T, eos, last_step, top_ends,
-                           out_tok, out_len, out_score, row_parent, n_alive, n_true);
+                           out_tok, out_len, out_score, row_parent, n_alive, n_true, n_alive_host);
         return tst_after_launch(name);
     }
     int32_t* alive = scratch_alive_pos;
@@ -887,7 +909,7 @@ int retire_compact_impl(const tst_rows* cur, const tst_rows* nxt, const int32_t*
                            sel_score, sel_fin, sel_nemit, lp, n_sent, (int)k, (int)T, last_step, top_ends, out_tok, out_len,
                            out_score, alive, n_true);
     }
-    hipLaunchKernelGGL(scan_alive_kernel, dim3(1), dim3(1024), 0, st, alive, pos, n_sent, n_alive);
+    hipLaunchKernelGGL(scan_alive_kernel, dim3(1), dim3(1024), 0, st, alive, pos, n_sent, n_alive, n_alive_host);
     if (n_sent > 0) {
         hipLaunchKernelGGL(gather_state_kernel, dim3(blocks_for(n_sent * k, 4)), dim3(256), 0, st, *cur, *nxt, sel_parent,
                            sel_tok, sel_score, sel_fin, sel_nemit, alive, pos, n_sent * k, (int)k, (int)step, (int)T,
@@ -958,24 +980,34 @@ extern "C" int tst_retire_compact_noalloc(const tst_rows* cur, const tst_rows* n
 
 namespace {
 
+// argmax_tok: the selected tokens, or NULL with keys: the arg-max keys of tst_ln_vocab_argmax_f32
 int greedy_retire_compact_impl(const int32_t* argmax_tok, const tst_rows* cur, const tst_rows* nxt, int32_t* sel_parent, int32_t* sel_tok,
                                float* sel_score, int32_t* sel_fin, int32_t* sel_nemit, const float* lp, int64_t n_sent, int64_t step,
                                int64_t T, int32_t eos, int last_step, int32_t* out_tok, int32_t* out_len, float* out_score,
-                               int32_t* scratch_alive_pos, int32_t* row_parent, int32_t* n_alive, void* stream, const int32_t* n_true) {
+                               int32_t* scratch_alive_pos, int32_t* row_parent, int32_t* n_alive, void* stream, const int32_t* n_true,
+                               const uint64_t* keys = nullptr, int32_t* n_alive_host = nullptr) {
+    const unsigned long long* kp = (const unsigned long long*)keys;
+    TST_REQUIRE(tst_aligned16(keys), TST_ERR_ARG, "tst_greedy_retire_compact: arg-max keys must be 16-byte aligned");
     if (n_sent > SMALL_TAIL_ROWS || n_sent <= 0) {
-        const int rc = tst_greedy_select(argmax_tok, n_sent, eos, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, cur, stream);
-        if (rc != TST_OK) return rc;
+        TST_REQUIRE((argmax_tok || kp) && sel_parent && sel_tok && sel_score && sel_fin && sel_nemit && rows_ok(cur, false), TST_ERR_ARG,
+                    "tst_greedy_retire_compact: null pointer");
+        if (n_sent > 0) {
+            hipLaunchKernelGGL(greedy_select_kernel, dim3(blocks_for(n_sent, 256)), dim3(256), 0, (hipStream_t)stream, argmax_tok, kp, n_sent,
+                               eos, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, *cur);
+            const int rc = tst_after_launch("tst_greedy_retire_compact");
+            if (rc != TST_OK) return rc;
+        }
         return retire_compact_impl(cur, nxt, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, lp, n_sent, 1, step, T, eos, last_step, 0,
                                    out_tok, out_len, out_score, scratch_alive_pos, row_parent, n_alive, stream, "tst_greedy_retire_compact",
-                                   n_true);
+                                   n_true, n_alive_host);
     }
-    TST_REQUIRE(argmax_tok && rows_ok(cur, false) && rows_ok(nxt, cur && cur->anc) && sel_parent && sel_tok && sel_score && sel_fin &&
+    TST_REQUIRE((argmax_tok || kp) && rows_ok(cur, false) && rows_ok(nxt, cur && cur->anc) && sel_parent && sel_tok && sel_score && sel_fin &&
                     sel_nemit && lp && out_tok && out_len && out_score && row_parent && n_alive,
                 TST_ERR_ARG, "tst_greedy_retire_compact: null pointer");
     TST_REQUIRE(step >= 0 && step < T, TST_ERR_ARG, "tst_greedy_retire_compact: bad sizes (need 0 <= step < T)");
-    hipLaunchKernelGGL(tail_small_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, *cur, *nxt, argmax_tok, sel_parent, sel_tok,
+    hipLaunchKernelGGL(tail_small_kernel<true>, dim3(1), dim3(1024), 0, (hipStream_t)stream, *cur, *nxt, argmax_tok, kp, sel_parent, sel_tok,
                        sel_score, sel_fin, sel_nemit, lp, (int)n_sent, 1, (int)step, (int)T, eos, last_step, 0, out_tok, out_len,
-                       out_score, row_parent, n_alive, n_true);
+                       out_score, row_parent, n_alive, n_true, n_alive_host);
     return tst_after_launch("tst_greedy_retire_compact");
 }
 
@@ -994,9 +1026,10 @@ int tst_greedy_retire_compact_bounded(const int32_t* argmax_tok, const tst_rows*
                                       int32_t* sel_tok, float* sel_score, int32_t* sel_fin, int32_t* sel_nemit, const float* lp,
                                       int64_t n_sent, int64_t step, int64_t T, int32_t eos, int last_step, int32_t* out_tok,
                                       int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent,
-                                      int32_t* n_alive, const int32_t* n_true, void* stream) {
+                                      int32_t* n_alive, const int32_t* n_true, const uint64_t* keys, int32_t* n_alive_host, void* stream) {
     return greedy_retire_compact_impl(argmax_tok, cur, nxt, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, lp, n_sent, step, T, eos,
-                                      last_step, out_tok, out_len, out_score, scratch_alive_pos, row_parent, n_alive, stream, n_true);
+                                      last_step, out_tok, out_len, out_score, scratch_alive_pos, row_parent, n_alive, stream, n_true, keys,
+                                      n_alive_host);
 }
 
 // The two retirement entry points with the true sentence count read from device memory (n_sent is then an upper bound):
@@ -1005,8 +1038,8 @@ int tst_retire_compact_bounded(const tst_rows* cur, const tst_rows* nxt, const i
                                const float* sel_score, const int32_t* sel_fin, const int32_t* sel_nemit, const float* lp, int64_t n_sent,
                                int64_t k, int64_t step, int64_t T, int32_t eos, int last_step, int top_ends, int32_t* out_tok,
                                int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent, int32_t* n_alive,
-                               const int32_t* n_true, void* stream) {
+                               const int32_t* n_true, int32_t* n_alive_host, void* stream) {
     return retire_compact_impl(cur, nxt, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, lp, n_sent, k, step, T, eos, last_step,
                                top_ends, out_tok, out_len, out_score, scratch_alive_pos, row_parent, n_alive, stream,
-                               "tst_select_step_run", n_true);
+                               "tst_select_step_run", n_true, n_alive_host);
 }

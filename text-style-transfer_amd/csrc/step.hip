@@ -79,13 +79,20 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
     const StepCtx c{m, R, stream, m->bf16 != 0};
     const int64_t esz = c.bf16 ? 2 : 4;
     // large fp32 steps: the final LayerNorm writes its rows k-major and the vocabulary projection stages both operands by LDS-DMA
-    const bool dma_vocab = !c.bf16 && m->ht != nullptr && R >= TST_DMA_MIN_ROWS && d % 16 == 0 && d <= 512;
+    // greedy decoding of a small fp32 batch: the step ends in the arg-max keys of its logits (tst_ln_vocab_argmax_f32)
+    const bool keys_out = m->argmax_keys != nullptr;
+    TST_REQUIRE(!keys_out || (!c.bf16 && phases == (TST_STEP_EMBED | TST_STEP_LAYERS | TST_STEP_VOCAB) && tst_vocab_argmax_ok(R, m->V, d)),
+                TST_ERR_UNSUPPORTED, "tst_tfm_step_run: argmax_keys needs fp32, all three phases and a shape tst_vocab_argmax_ok accepts");
+    const bool dma_vocab = !keys_out && !c.bf16 && m->ht != nullptr && R >= TST_DMA_MIN_ROWS && d % 16 == 0 && d <= 512;
     TST_REQUIRE(!dma_vocab || (m->ld_ht % 4 == 0 && m->ld_ht >= (R + 127) / 128 * 128), TST_ERR_ARG,
                 "tst_tfm_step_run: ld_ht must be a multiple of 4 and at least the rows rounded up to 128");
 
     if (phases & TST_STEP_EMBED) {
         TST_REQUIRE(tok && m->emb && m->pe, TST_ERR_ARG, "tst_tfm_step_run: null embedding input");
-        if (m->z != nullptr) {   // embedding, positional row and the sentence's conditioning vector in one pass
+        if (keys_out) {
+            TST_REQUIRE(m->z == nullptr || sent != nullptr, TST_ERR_ARG, "tst_tfm_step_run: z without sent");
+            TST_TRY(tst_embed_posadd_clear_f32(tok, m->emb, m->pe + t * d, m->scale, m->z, sent, m->x, m->argmax_keys, R, d, m->V, stream));
+        } else if (m->z != nullptr) {   // embedding, positional row and the sentence's conditioning vector in one pass
             TST_REQUIRE(sent != nullptr, TST_ERR_ARG, "tst_tfm_step_run: z without sent");
             TST_TRY(tst_embed_posadd_rows_f32(tok, m->emb, m->pe + t * d, nullptr, m->scale, m->z, sent, m->x, R, d, m->V, stream));
         } else {
@@ -177,13 +184,17 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
             TST_TRY(c.ln_gemm(L.ln_ff_g, L.ln_ff_b, L.w1, L.ld_w1, L.b1, m->ff, m->d_ff, m->d_ff, 1));
             TST_TRY(c.gemm(m->ff, m->d_ff, L.w2, L.ld_w2, L.b2, m->x, d, m->x, d, d, m->d_ff, 0, false));
         }
-        if (chain || ln_fuse) {}   // the last chain wrote the final LayerNorm k-major / the last residual product wrote it into h
+        if (chain || ln_fuse || keys_out) {}   // the last chain wrote the final LayerNorm k-major / the last residual product wrote it
+                                               // into h / the arg-max kernel normalises the rows itself
         else if (dma_vocab) TST_TRY(tst_layernorm_t_f32(m->x, m->ln_g, m->ln_b, m->eps, m->ht, m->ld_ht, R, d, stream));
         else TST_TRY(c.layernorm(m->x, m->ln_g, m->ln_b, m->h));
     }
     if (phases & TST_STEP_VOCAB) {
         TST_REQUIRE(m->wout != nullptr, TST_ERR_ARG, "tst_tfm_step_run: null output projection");
-        if (dma_vocab)
+        if (keys_out)
+            TST_TRY(tst_ln_vocab_argmax_f32(m->x, m->ln_g, m->ln_b, m->eps, (const float*)m->wout, m->ld_wout, m->bout, m->argmax_keys, R, m->V,
+                                            d, stream));
+        else if (dma_vocab)
             TST_TRY(tst_gemm_dma_f32(m->ht, m->ld_ht, (const float*)m->wout, m->ld_wout, m->bout, (float*)m->logits, m->ld_logits, R, m->V, d,
                                      tst_vocab_variant(), stream));   // nontemporal stores: the logits leave the caches before they are read
         else if (c.bf16 && m->part != nullptr && tst_vocab_stats_ok(R, m->V, d))
@@ -276,7 +287,10 @@ extern "C" int tst_select_step_run(const tst_select_step* s, const tst_rows* cur
     TST_REQUIRE(s->k >= 1 && s->k <= 8 && (k_in == 1 || k_in == s->k) && n_sent >= 0, TST_ERR_ARG, "tst_select_step_run: bad sizes");
     const int64_t R = n_sent * k_in;
     if (s->k == 1) {
-        if (s->sample) {
+        TST_REQUIRE(s->am_keys == nullptr || !s->sample, TST_ERR_ARG, "tst_select_step_run: am_keys and sampling cannot be combined");
+        if (s->am_keys != nullptr) {
+            // the step left arg-max keys instead of logits
+        } else if (s->sample) {
             TST_TRY(s->bf16_logits ? tst_sample_rows_bf16(s->logits, s->ld_logits, R, s->V, s->temperature, s->seed, sample_step,
                                                           cur->sent, s->am, stream)
                                    : tst_sample_rows_f32((const float*)s->logits, s->ld_logits, R, s->V, s->temperature, s->seed,
@@ -285,9 +299,10 @@ extern "C" int tst_select_step_run(const tst_select_step* s, const tst_rows* cur
             TST_TRY(s->bf16_logits ? tst_argmax_rows_bf16(s->logits, s->ld_logits, R, s->V, s->am, stream)
                                    : tst_argmax_rows_f32((const float*)s->logits, s->ld_logits, R, s->V, s->am, stream));
         }
-        return tst_greedy_retire_compact_bounded(s->am, cur, nxt, s->sel_parent, s->sel_tok, s->sel_score, s->sel_fin, s->sel_nemit, s->lp,
-                                                 n_sent, step, s->T, s->eos, last_step, s->out_tok, s->out_len, s->out_score,
-                                                 s->scratch_alive_pos, s->row_parent, s->n_alive, s->n_sent_dev, stream);
+        return tst_greedy_retire_compact_bounded(s->am_keys != nullptr ? nullptr : s->am, cur, nxt, s->sel_parent, s->sel_tok, s->sel_score,
+                                                 s->sel_fin, s->sel_nemit, s->lp, n_sent, step, s->T, s->eos, last_step, s->out_tok,
+                                                 s->out_len, s->out_score, s->scratch_alive_pos, s->row_parent, s->n_alive, s->n_sent_dev,
+                                                 s->am_keys, s->n_alive_host, stream);
     } else {
         if (s->bf16_logits && s->part != nullptr && tst_vocab_stats_ok(R, s->V, s->stats_k))
             TST_TRY(tst_topk_from_stats_bf16(s->logits, s->ld_logits, s->part, s->n_slices, R, s->V, s->k, s->top_val, s->top_idx, s->lse,
@@ -301,5 +316,5 @@ extern "C" int tst_select_step_run(const tst_select_step* s, const tst_rows* cur
     }
     return tst_retire_compact_bounded(cur, nxt, s->sel_parent, s->sel_tok, s->sel_score, s->sel_fin, s->sel_nemit, s->lp, n_sent, s->k, step,
                                       s->T, s->eos, last_step, s->top_ends, s->out_tok, s->out_len, s->out_score, s->scratch_alive_pos,
-                                      s->row_parent, s->n_alive, s->n_sent_dev, stream);
+                                      s->row_parent, s->n_alive, s->n_sent_dev, s->n_alive_host, stream);
 }

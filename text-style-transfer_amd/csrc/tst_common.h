@@ -9,17 +9,21 @@
 
 void tst_set_error(const char* fmt, ...);
 
-// select.hip: the retirement entry points with the true sentence count read from device memory (n_sent an upper bound)
+// select.hip: the retirement entry points with the true sentence count read from device memory (n_sent an upper bound),
+// an optional second (host-visible) target of the survivor count, and arg-max keys in place of the token list
 int tst_retire_compact_bounded(const tst_rows* cur, const tst_rows* nxt, const int32_t* sel_parent, const int32_t* sel_tok,
                                const float* sel_score, const int32_t* sel_fin, const int32_t* sel_nemit, const float* lp, int64_t n_sent,
                                int64_t k, int64_t step, int64_t T, int32_t eos, int last_step, int top_ends, int32_t* out_tok,
                                int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent, int32_t* n_alive,
-                               const int32_t* n_true, void* stream);
+                               const int32_t* n_true, int32_t* n_alive_host, void* stream);
 int tst_greedy_retire_compact_bounded(const int32_t* argmax_tok, const tst_rows* cur, const tst_rows* nxt, int32_t* sel_parent,
                                       int32_t* sel_tok, float* sel_score, int32_t* sel_fin, int32_t* sel_nemit, const float* lp,
                                       int64_t n_sent, int64_t step, int64_t T, int32_t eos, int last_step, int32_t* out_tok,
                                       int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent,
-                                      int32_t* n_alive, const int32_t* n_true, void* stream);
+                                      int32_t* n_alive, const int32_t* n_true, const uint64_t* keys, int32_t* n_alive_host, void* stream);
+// rowops.hip: tst_embed_posadd_f32 / tst_embed_posadd_rows_f32 (z may be NULL) that also clears clear_keys[0..R) (arg-max keys)
+int tst_embed_posadd_clear_f32(const int32_t* tok, const float* emb, const float* pe, float scale, const float* z, const int32_t* zidx,
+                               float* x, uint64_t* clear_keys, int64_t R, int64_t d, int64_t V, void* stream);
 
 // attn_mfma.hip: the matrix-core cross-attention of beam groups (used by tst_attn_cross_group_f32)
 int tst_cross_mfma_ok(int64_t S, int64_t dh, int64_t group);

@@ -51,6 +51,13 @@ def _lp_on_device(max_len, alpha, dev):
 LAG_MAX_ROWS = 0 if __import__('os').environ.get('TST_NO_LAG') else 2048   # sentences x beams up to which the loop does not wait for a step's survivor count before the next launch
 
 
+# Greedy steps of sessions that offer it end in arg-max keys instead of logits (one kernel for the final LayerNorm, the vocabulary
+# projection and the arg-max); the lagged loop lets the kernel that counts the survivors store the count into page-locked host
+# memory itself instead of queueing a copy behind every step.  Either can be switched off for measurements; same outputs.
+_os = __import__('os')
+KEYS_ON = not _os.environ.get('TST_NO_ARGMAX_KEYS')
+HOST_COUNT_ON = not _os.environ.get('TST_NO_HOST_COUNT')
+
 _PINNED = {}
 
 
@@ -123,6 +130,9 @@ class DecodeLoop:
             self.top_idx = torch.zeros((R, beam), **i32)
             self.lse = torch.zeros(R, dtype=torch.float32, device=dev)
         self.tail = None   # kernels.SelectPlan, made at the first step (it needs the session's logits buffer)
+        self.keys = None   # arg-max keys of greedy steps (see _keys_for)
+        if (KEYS_ON and beam == 1 and sample is None and gumbel is None and getattr(session, 'keys_ok', None) is not None):
+            self.keys = torch.zeros((R, K.ARGMAX_SLOTS), dtype=torch.int64, device=dev)
         # Soft decoding (``gumbel=True`` of /root/reference/src/inference.py:104-105,136-138): the next input of a row
         # is the distribution softmax((softmax(logits) + G) / temperature) instead of a token id; the token that
         # decides about EOS is still the arg-max / sample of the raw logits.  gumbel = (temperature, prefix [B, V],
@@ -145,6 +155,12 @@ class DecodeLoop:
         self.rows_stepped = 0
         self.select_log = None   # set to a timing.LaunchTimer to time every log-softmax/top-k launch (work = bytes)
 
+    def _keys_for(self, R, t, keep_logits):
+        """The keys buffer when step t (of R rows) may end in arg-max keys instead of logits, else None."""
+        if self.keys is None or self.select_log is not None or t < keep_logits or not self.s.keys_ok(R):
+            return None
+        return self.keys
+
     def run(self, keep_logits=0):
         """Runs the loop.  Returns (out_tok [B, pos0 + T + 1], out_len [B], out_score [B]) on the device; with
         ``keep_logits`` > 0 also records (logits, sentence ids of the rows) of the first steps in
@@ -164,7 +180,10 @@ class DecodeLoop:
             k_in = 1 if t == 0 else k      # rows per sentence going into this step
             R = n_sent * k_in
             s.rows_per_sentence = k_in     # sessions that share work among the beams of a sentence read this
-            if self.gumbel is None:
+            keys = self._keys_for(R, t, keep_logits)
+            if keys is not None:
+                logits = s.step(self.cur, R, pos0 + t, keys=keys)
+            elif self.gumbel is None:
                 logits = s.step(self.cur, R, pos0 + t)
             else:
                 logits = s.step(self.cur, R, t, soft=self.dist_in)
@@ -182,6 +201,7 @@ class DecodeLoop:
                 elif logits.data_ptr() != self.tail.logits_ptr:
                     _check_logits(logits, R, s.V)
                     self.tail.set_logits(logits)
+                self.tail.set_keys(keys)
                 self.tail.run(self.cur, self.nxt, n_sent, k_in, pos0 + t, t, t == T - 1)
             else:
                 if k == 1:
@@ -227,7 +247,8 @@ class DecodeLoop:
             k_in = 1 if t == 0 else k
             R = bound * k_in
             s.rows_per_sentence = k_in
-            logits = s.step(self.cur, R, pos0 + t)
+            keys = self._keys_for(R, t, keep_logits)
+            logits = s.step(self.cur, R, pos0 + t) if keys is None else s.step(self.cur, R, pos0 + t, keys=keys)
             if t < keep_logits:
                 self.kept.append((logits[:R, :s.V].clone(), self.cur.sent[:R].clone(), self.cur.fin[:R].clone()))
             if self.tail is None:
@@ -241,8 +262,11 @@ class DecodeLoop:
                 _check_logits(logits, R, s.V)
                 self.tail.set_logits(logits)
             self.tail.set_counts(counts[t % 2], counts[(t - 1) % 2] if t > 0 else None)
+            self.tail.set_keys(keys)
+            self.tail.set_count_host(host.data_ptr() + 4 * (t % 2) if HOST_COUNT_ON else None)
             self.tail.run(self.cur, self.nxt, bound, k_in, pos0 + t, t, t == T - 1)
-            host[t % 2:t % 2 + 1].copy_(counts[t % 2], non_blocking=True)
+            if not HOST_COUNT_ON:
+                host[t % 2:t % 2 + 1].copy_(counts[t % 2], non_blocking=True)
             events[t % 2].record()
             last = events[t % 2]
             self.cur, self.nxt = self.nxt, self.cur

@@ -108,6 +108,39 @@ def ln_gemm(x, gamma, beta, h, wt, bias, out, n_rows, n_cols=None, act=0, eps=1e
          n_rows, N, K, int(act), _stream())
 
 
+def vocab_argmax_ok(n_rows, n_cols, d):
+    """Whether ``ln_vocab_argmax`` (and the keys output of a transformer step) accepts this shape."""
+    return bool(_lib._dll.tst_vocab_argmax_ok(n_rows, n_cols, d))
+
+
+def ln_vocab_argmax(x, gamma, beta, wt, bias, keys, n_rows, n_cols=None, eps=1e-5):
+    """keys[:n_rows] (int64 bit patterns [rows, ARGMAX_SLOTS], ZERO on entry) = arg-max keys of LayerNorm(x[:n_rows]) @ wt[:, :N]
+    + bias: final LayerNorm, vocabulary projection and arg-max as one kernel; ``tokens_of_keys`` decodes them."""
+    for t, nm in ((x, 'x'), (gamma, 'gamma'), (beta, 'beta')):
+        _chk(t, torch.float32, nm)
+    _chk(keys, torch.int64, 'keys')
+    for t, nm in ((wt, 'wt'), (bias, 'bias')):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1):
+            raise ValueError('%s must be an fp32 GPU tensor with unit inner stride' % nm)
+    K = x.shape[1]
+    N = wt.shape[1] if n_cols is None else n_cols
+    assert wt.shape[0] == K and x.shape[0] >= n_rows and keys.numel() >= n_rows * ARGMAX_SLOTS
+    assert gamma.numel() == K and beta.numel() == K and (bias is None or bias.numel() >= N)
+    call('tst_ln_vocab_argmax_f32', _p(x), _p(gamma), _p(beta), float(eps), _p(wt), wt.stride(0), _p(bias), _p(keys), n_rows, N, K, _stream())
+
+
+ARGMAX_SLOTS = 16   # TST_ARGMAX_SLOTS of include/tst_hip.h
+
+
+def tokens_of_keys(keys):
+    """Token ids (int32) of arg-max keys [rows, ARGMAX_SLOTS]: the largest key of a row as an UNSIGNED number decides; key 0 =
+    no candidate = token 0, else the complement of the lower 32 bits."""
+    top = -0x8000000000000000
+    best = (keys.view(-1, ARGMAX_SLOTS) ^ top).max(dim=1).values ^ top   # unsigned order on signed storage
+    low = best & 0xffffffff
+    return torch.where(best == 0, torch.zeros_like(low), 0xffffffff - low).to(torch.int32)
+
+
 def chain_ok(n_rows, d, k1, n2):
     return bool(_lib._dll.tst_chain_ok(n_rows, d, k1, n2))
 
@@ -389,7 +422,16 @@ class StepPlan:
             emb=_p(emb), pe=_p(pe), scale=float(scale), eps=float(eps), z=_p(z), mask=_p(mask), kvrow=_p(kvrow), ln_g=_p(ln[0]), ln_b=_p(ln[1]),
             wout=_p(wout), bout=_p(bout), ld_wout=wout.stride(0), x=_p(x), h=_p(h), q=_p(q), a=_p(a), ff=_p(ff), logits=_p(logits),
             ld_logits=logits.stride(0), layers=self._layers, ht=_p(ht), ld_ht=0 if ht is None else ht.stride(0),
-            part=_p(part), n_slices=(V + 63) // 64)
+            part=_p(part), n_slices=(V + 63) // 64, argmax_keys=None)
+        self._keys = None
+
+    def set_keys(self, keys):
+        """``keys`` (int64 [>= slab_rows, ARGMAX_SLOTS], or None): the coming calls of ``run`` end in the arg-max keys of the logits instead of the
+        logits (``tst_tfm_step.argmax_keys``: fp32, all phases, a shape ``vocab_argmax_ok`` accepts)."""
+        if keys is not None:
+            _chk(keys, torch.int64, 'keys')
+        self._keys = keys
+        self.c.argmax_keys = _p(keys)
 
     def run(self, rows, n_rows, t, phases):
         call('tst_tfm_step_run', self.c, _p(rows.tok), _p(rows.anc), _p(rows.sent), n_rows, t, phases, _stream())
@@ -442,8 +484,10 @@ class SelectPlan:
             temperature=float(sample[0]) if sample is not None else 1.0, seed=(int(sample[1]) & 0xffffffff) if sample is not None else 0,
             out_tok=_p(out_tok), out_len=_p(out_len), out_score=_p(out_score), scratch_alive_pos=_p(scratch),
             row_parent=_p(row_parent), n_alive=_p(n_alive), n_sent_dev=None,
-            part=None if stats is None else _p(stats[0]), n_slices=(V + 63) // 64, stats_k=0 if stats is None else int(stats[1]))
+            part=None if stats is None else _p(stats[0]), n_slices=(V + 63) // 64, stats_k=0 if stats is None else int(stats[1]),
+            am_keys=None, n_alive_host=None)
         self.logits_ptr = _p(logits)
+        self._keys = None
 
     def set_logits(self, logits):
         """A model that returns a new logits tensor every step (any foreign callable)."""
@@ -458,6 +502,17 @@ class SelectPlan:
         entering the step is read from when ``n_sent`` of ``run`` is an upper bound."""
         self._keep_counts = (n_alive, n_sent_dev)
         self.c.n_alive, self.c.n_sent_dev = _p(n_alive), _p(n_sent_dev)
+
+    def set_keys(self, keys):
+        """``keys`` (int64, or None): the coming steps decode their tokens from these arg-max keys (greedy selection only)
+        instead of reading the logits."""
+        self._keys = keys
+        self.c.am_keys = _p(keys)
+
+    def set_count_host(self, addr):
+        """``addr`` (int, or None): device-visible address of 4 bytes of page-locked host memory that also receives the number
+        of surviving sentences of the coming steps."""
+        self.c.n_alive_host = addr
 
     def run(self, cur, nxt, n_sent, k_in, step, sample_step, last_step):
         call('tst_select_step_run', self.c, cur.struct(), nxt.struct(), n_sent, k_in, step, sample_step, int(last_step), _stream())

@@ -298,13 +298,28 @@ class TransformerSession:
             self._plans[anc_ld] = plan
         return plan
 
-    def step(self, rows, n, t, soft=None):
+    def keys_ok(self, n):
+        """Whether a step of n rows can end in arg-max keys instead of logits (``step(..., keys=)``)."""
+        return self.dec.event_log is None and K.vocab_argmax_ok(n, self.V, self.dec.d)
+
+    def step(self, rows, n, t, soft=None, keys=None):
         """Logits of the next token for rows 0..n-1 at position t.  ``soft`` ([>= n, Vp] fp32 token distributions,
         see ``kernels.soft_embed``) replaces the lookup of ``rows.tok`` by the expected embedding.  The launches of
-        the step are issued by one native call (two when the vocabulary projection is being timed)."""
+        the step are issued by one native call (two when the vocabulary projection is being timed).
+        ``keys`` (int64 [>= n], only when ``keys_ok(n)``): the step ends in the arg-max keys of its logits
+        (``kernels.ln_vocab_argmax``) and the returned logits buffer is NOT written."""
         dec = self.dec
         plan = self._plan(rows.anc.shape[1])
         plan.c.group = self.rows_per_sentence      # set by the decode loop: 1 at the first step, then the beam size
+        if keys is not None:
+            if soft is not None or not self.keys_ok(n):
+                raise ValueError('arg-max keys need token inputs and a shape keys_ok accepts')
+            plan.set_keys(keys)
+            try:
+                plan.run(rows, n, t, K.STEP_EMBED | K.STEP_LAYERS | K.STEP_VOCAB)
+            finally:
+                plan.set_keys(None)
+            return self.logits
         body = K.STEP_LAYERS
         if soft is None:
             body |= K.STEP_EMBED
