@@ -459,14 +459,44 @@ __global__ __launch_bounds__(64) void gemm_f32_skinny_kernel(const float* __rest
             for (int j = 0; j < NT; ++j)
                 acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s], sk_get<NT>(bv[s], j), acc[j], 0, 0, 0);
     };
+    // residual values of the lane's results, requested before the k loop (scalar path of the epilogue: one-column strips)
+    float rres[4];
+    if (HAS_RES && NT == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = min(m0 + 4 * kq + i, M - 1);
+            rres[i] = res[(int64_t)row * ldr + min(col0, N - 1)];
+        }
+    }
     const int k_full = K / KC * KC;
-    if (k_full > 0) load_full(a_cur, b_cur, 0);
-    for (int k0 = 0; k0 < k_full; k0 += 2 * KC) {
-        if (k0 + KC < k_full) load_full(a_nxt, b_nxt, k0 + KC);
-        mfma_full(a_cur, b_cur);
-        if (k0 + KC < k_full) {
-            if (k0 + 2 * KC < k_full) load_full(a_cur, b_cur, k0 + 2 * KC);
-            mfma_full(a_nxt, b_nxt);
+    if (NT == 1 && k_full >= 4 * KC) {
+        // long inner dimension (one-column strips: the wave's registers allow it): chunks two ahead of the MFMAs that use them,
+        // the 32 MFMAs of a chunk are shorter than a load from the L2; same ascending order of k
+        float a_nx2[STEPS];
+        wvec b_nx2[STEPS];
+        load_full(a_cur, b_cur, 0);
+        load_full(a_nxt, b_nxt, KC);
+        for (int k0 = 0; k0 < k_full; k0 += 3 * KC) {
+            if (k0 + 2 * KC < k_full) load_full(a_nx2, b_nx2, k0 + 2 * KC);
+            mfma_full(a_cur, b_cur);
+            if (k0 + KC < k_full) {
+                if (k0 + 3 * KC < k_full) load_full(a_cur, b_cur, k0 + 3 * KC);
+                mfma_full(a_nxt, b_nxt);
+            }
+            if (k0 + 2 * KC < k_full) {
+                if (k0 + 4 * KC < k_full) load_full(a_nxt, b_nxt, k0 + 4 * KC);
+                mfma_full(a_nx2, b_nx2);
+            }
+        }
+    } else {
+        if (k_full > 0) load_full(a_cur, b_cur, 0);
+        for (int k0 = 0; k0 < k_full; k0 += 2 * KC) {
+            if (k0 + KC < k_full) load_full(a_nxt, b_nxt, k0 + KC);
+            mfma_full(a_cur, b_cur);
+            if (k0 + KC < k_full) {
+                if (k0 + 2 * KC < k_full) load_full(a_cur, b_cur, k0 + 2 * KC);
+                mfma_full(a_nxt, b_nxt);
+            }
         }
     }
     // the last K % KC values, four at a time: one dword of A per lane and step
@@ -502,7 +532,7 @@ __global__ __launch_bounds__(64) void gemm_f32_skinny_kernel(const float* __rest
             for (int j = 0; j < NT; ++j) {
                 if (col0 + j < N) {
                     float o = v[j];
-                    if (HAS_RES) o = o + res[(int64_t)row * ldr + col0 + j];
+                    if (HAS_RES) o = o + (NT == 1 ? rres[i] : res[(int64_t)row * ldr + col0 + j]);
                     cp[j] = o;
                 }
             }
