@@ -4,6 +4,7 @@
 // to combine the four waves of a workgroup.
 #include "tst_common.h"
 #include <limits.h>
+#include <stdlib.h>
 #include <atomic>
 #include <math.h>
 
@@ -730,7 +731,17 @@ __global__ __launch_bounds__(1024) void tail_small_kernel(tst_rows cur, tst_rows
     }
 }
 
-constexpr int64_t SMALL_TAIL_ROWS = 160;
+// rows up to which one workgroup does the whole tail (measured crossover against the separate kernels);
+// TST_SMALL_TAIL_ROWS=<n> in the environment moves it (measurements; at most 1024: one thread per row)
+int64_t small_tail_rows() {
+    static const int64_t v = [] {
+        const char* e = getenv("TST_SMALL_TAIL_ROWS");
+        const long long n = e != nullptr ? atoll(e) : 160;
+        return (int64_t)(n < 0 ? 0 : n > 1024 ? 1024 : n);
+    }();
+    return v;
+}
+#define SMALL_TAIL_ROWS small_tail_rows()
 
 inline unsigned blocks_for(int64_t n, int per) { return (unsigned)((n + per - 1) / per); }
 
