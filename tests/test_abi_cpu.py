@@ -71,6 +71,48 @@ def test_argument_errors_are_reported_not_crashed():
         _lib.call('tst_select_step_run', _lib.TstSelectStep(k=4), rows, rows, 1, 2, 0, 0, 0, None)
 
 
+def test_argmax_keys_entry_points_and_key_decoding():
+    """The fused LayerNorm + projection + arg-max entry point refuses bad calls on the host, its shape predicate is a pure
+    function, a step plan with keys refuses calls the fused kernel cannot serve, and the host-side decoding of keys follows
+    the documented format (unsigned maximum over a row's slots; 0 = no candidate = token 0; else ~low word)."""
+    import torch
+    from tst_amd import _lib, kernels as K
+    assert _lib._dll.tst_vocab_argmax_ok(256, 32000, 256) == 1
+    assert _lib._dll.tst_vocab_argmax_ok(257, 32000, 256) == 0      # 3 x 250 tiles of 128 x 128
+    assert _lib._dll.tst_vocab_argmax_ok(8, 100, 384) == 0          # rows of 256 or 512 floats only
+    assert _lib._dll.tst_vocab_argmax_ok(0, 100, 256) == 0
+    with pytest.raises(_lib.TstError, match='tst_ln_vocab_argmax_f32: null pointer'):
+        _lib.call('tst_ln_vocab_argmax_f32', 16, 16, 16, 1e-5, 16, 100, None, None, 4, 100, 256, None)
+    with pytest.raises(_lib.TstError, match='ldw'):
+        _lib.call('tst_ln_vocab_argmax_f32', 16, 16, 16, 1e-5, 16, 98, None, 16, 4, 100, 256, None)
+    with pytest.raises(_lib.TstError, match='tst_vocab_argmax_ok'):
+        _lib.call('tst_ln_vocab_argmax_f32', 16, 16, 16, 1e-5, 16, 100, None, 16, 4, 100, 128, None)
+    layers = (_lib.TstTfmLayer * 1)()
+    plan = _lib.TstTfmStep(n_layers=1, d=256, heads=2, d_ff=16, V=10, n_pos=4, slab_rows=2, layers=layers, x=16, h=16, a=16, ff=16,
+                           logits=16, argmax_keys=16)
+    with pytest.raises(_lib.TstError, match='argmax_keys needs'):
+        _lib.call('tst_tfm_step_run', plan, None, None, None, 2, 0, 6, None)       # not all three phases
+    plan.bf16 = 1
+    with pytest.raises(_lib.TstError, match='argmax_keys needs'):
+        _lib.call('tst_tfm_step_run', plan, None, None, None, 2, 0, 7, None)       # bf16 plan
+    rows = _lib.TstRows()
+    with pytest.raises(_lib.TstError, match='am_keys and sampling'):
+        _lib.call('tst_select_step_run', _lib.TstSelectStep(k=1, sample=1, am_keys=16), rows, rows, 1, 1, 0, 0, 0, None)
+
+    def key(bits, col):
+        u = (~bits & 0xffffffff) if bits & 0x80000000 else bits | 0x80000000
+        v = (u << 32) | (~col & 0xffffffff)
+        return v - (1 << 64) if v >= (1 << 63) else v          # as stored in an int64 tensor
+    keys = torch.zeros((4, K.ARGMAX_SLOTS), dtype=torch.int64)
+    keys[0, 3], keys[0, 9] = key(0x3f800000, 17), key(0x40000000, 5)     # 1.0 at 17, 2.0 at 5 -> 5
+    keys[1, 0], keys[1, 15] = key(0xbf800000, 7), key(0xc0000000, 2)     # -1.0 at 7, -2.0 at 2 -> 7
+    keys[2, 4], keys[2, 5] = key(0x3f800000, 900), key(0x3f800000, 31)   # equal values -> the smaller column
+    assert K.tokens_of_keys(keys).tolist() == [5, 7, 31, 0]              # row 3: no candidate -> token 0
+    keys[3, 1] = key(0xbf800000, 12)                                       # a negative value beats "no candidate"
+    keys[3, 2] = key(0x00000000, 40)                                       # and +0 beats it
+    assert K.tokens_of_keys(keys).tolist() == [5, 7, 31, 40]
+
+
 def test_no_product_module_touches_the_oracle():
     pkg = os.path.join(ROOT, 'text-style-transfer_amd')
     for dirpath, _, files in os.walk(pkg):
