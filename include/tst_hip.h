@@ -40,7 +40,8 @@ extern "C" {
  * 106 = 105 + tst_chain_ok, tst_chain_f32, tst_gemm_res_ln_ok, tst_gemm_res_ln_bf16,
  * tst_embed_posadd_rows_f32 (additions only);
  * 107 = 106 + tst_vocab_argmax_ok, tst_ln_vocab_argmax_f32, tst_tfm_step.argmax_keys, tst_select_step.am_keys /
- * n_alive_host (the structs grew at their ends). */
+ * n_alive_host (the structs grew at their ends);
+ * 108 = 107 + tst_gru_cell_fused_tab_f32, tst_gru_cell_step_tab_f32, tst_gru_step.gi_tab / ld_gi_tab. */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
@@ -232,6 +233,21 @@ int tst_gru_cell_fused_ok(int64_t E, int64_t H);
 int tst_gru_cell_fused_f32(const float* x, int64_t ldx, const float* h, int64_t ldh, const float* wih, int64_t ld_wih,
                            const float* bih, const float* whh, int64_t ld_whh, const float* bhh, float* h_out, int64_t ldo,
                            int64_t R, int64_t E, int64_t H, void* stream);
+
+/* The GRU cell step of a layer whose input is a plain embedding lookup, with the input product taken from a table instead of
+ * computed: gi_tab [V][ld_tab >= 3H] holds bias_ih + embedding[v] * Wih for every vocabulary entry v (the caller makes it once
+ * per model with tst_gemm_mfma_f32 over the embedding matrix: the same fma chain per element as the product inside
+ * tst_gru_cell_fused_f32 / the first product of the three-call form, hence the same bits), and row r uses row tok[r] of it (ids
+ * clamped to 0 .. V-1 as in tst_embed_posadd_f32).  Replaces nn.Embedding + the input half of nn.GRU for one time step
+ * (/root/reference/src/inference.py:170-177 steps such a decoder); half the matrix work of the cell.
+ * tst_gru_cell_fused_tab_f32: the recurrent product and the update in one kernel (H % 64 == 0), h_out must not overlap h;
+ * h_out_t as in tst_gru_cell_fused_t_f32, or NULL.  tst_gru_cell_step_tab_f32: the update alone, gh [R][3H] given (h_out may
+ * alias h).  Same results as tst_gru_cell_fused_f32 / tst_gru_cell_step_f32 on x = embedding[tok]. */
+int tst_gru_cell_fused_tab_f32(const float* gi_tab, int64_t ld_tab, const int32_t* tok, int64_t V, const float* h, int64_t ldh,
+                               const float* whh, int64_t ld_whh, const float* bhh, float* h_out, int64_t ldo, float* h_out_t,
+                               int64_t ldt, int64_t R, int64_t H, void* stream);
+int tst_gru_cell_step_tab_f32(const float* gi_tab, int64_t ld_tab, const int32_t* tok, int64_t V, const float* gh, const float* h,
+                              float* h_out, int64_t R, int64_t H, void* stream);
 
 /* tst_gru_cell_fused_f32 that ALSO stores the new state k-major, h_out_t[j][r] = h_out[r][j] (ldt >= R floats per hidden unit):
  * the A operand layout of tst_gemm_dma_f32, so that the output projection H -> V of a large batch stages both operands by
@@ -483,6 +499,11 @@ typedef struct tst_gru_step {
                                TST_STEP_FUSED_CELL of at least TST_DMA_MIN_ROWS rows and V >= 2048 writes it
                                (tst_gru_cell_fused_t_f32) and its output projection is tst_gemm_dma_f32.  Same logits. */
     int64_t ld_ht;          /* a multiple of 4, >= rows rounded up to a multiple of 128 */
+    const float* gi_tab;    /* optional: [V][ld_gi_tab >= 3H] = bih + emb[v] * Wih of layer 0 for every token v.  When set, a call
+                               with TST_STEP_EMBED and TST_STEP_LAYERS of a plan without `extra` does not compute the embeddings
+                               (x is NOT written) nor layer 0's input product: its cell reads gi_tab[tok[r]]
+                               (tst_gru_cell_fused_tab_f32 / tst_gru_cell_step_tab_f32).  Same logits. */
+    int64_t ld_gi_tab;
 } tst_gru_step;
 
 /* phases as for tst_tfm_step_run (TST_STEP_EMBED | TST_STEP_LAYERS | TST_STEP_VOCAB). */

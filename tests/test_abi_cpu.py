@@ -30,7 +30,7 @@ def test_binding_covers_header_and_version():
     import tst_amd
     from tst_amd import _lib
     assert sorted(_lib.EXPORTS) == declared_symbols()
-    assert tst_amd.version() == 107
+    assert tst_amd.version() == 108
 
 
 def test_argument_errors_are_reported_not_crashed():
@@ -111,6 +111,26 @@ def test_argmax_keys_entry_points_and_key_decoding():
     keys[3, 1] = key(0xbf800000, 12)                                       # a negative value beats "no candidate"
     keys[3, 2] = key(0x00000000, 40)                                       # and +0 beats it
     assert K.tokens_of_keys(keys).tolist() == [5, 7, 31, 40]
+
+
+def test_gi_table_entry_points_check_their_arguments():
+    from tst_amd import _lib
+    with pytest.raises(_lib.TstError, match='tst_gru_cell_fused_tab_f32: null pointer'):
+        _lib.call('tst_gru_cell_fused_tab_f32', None, 192, 16, 10, 16, 64, 16, 192, None, 32, 64, None, 0, 4, 64, None)
+    with pytest.raises(_lib.TstError, match='H %% 64'.replace('%%', '%')):
+        _lib.call('tst_gru_cell_fused_tab_f32', 16, 96, 16, 10, 16, 32, 16, 96, None, 32, 32, None, 0, 4, 32, None)
+    with pytest.raises(_lib.TstError, match='leading dimensions'):
+        _lib.call('tst_gru_cell_fused_tab_f32', 16, 100, 16, 10, 16, 64, 16, 192, None, 32, 64, None, 0, 4, 64, None)
+    with pytest.raises(_lib.TstError, match='must not overlap'):
+        _lib.call('tst_gru_cell_fused_tab_f32', 16, 192, 16, 10, 1024, 64, 16, 192, None, 1024, 64, None, 0, 4, 64, None)
+    with pytest.raises(_lib.TstError, match='tst_gru_cell_step_tab_f32: null pointer'):
+        _lib.call('tst_gru_cell_step_tab_f32', 16, 192, None, 10, 16, 16, 16, 4, 64, None)
+    with pytest.raises(_lib.TstError, match='ld_tab'):
+        _lib.call('tst_gru_cell_step_tab_f32', 16, 100, 16, 10, 16, 16, 16, 4, 64, None)
+    gl = (_lib.TstGruLayer * 1)()
+    gplan = _lib.TstGruStep(n_layers=1, E=8, H=8, V=10, rows=2, layers=gl, x=16, gi=16, gh=16, logits=16, gi_tab=16, ld_gi_tab=8)
+    with pytest.raises(_lib.TstError, match='gi_tab needs tok'):
+        _lib.call('tst_gru_step_run', gplan, None, None, 2, 7, None)
 
 
 def test_no_product_module_touches_the_oracle():

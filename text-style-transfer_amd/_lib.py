@@ -60,7 +60,7 @@ class TstGruStep(ctypes.Structure):
     _fields_ = [('n_layers', c_i32), ('E', c_i32), ('H', c_i32), ('V', c_i32), ('rows', c_i64),
                 ('emb', c_vp), ('extra', c_vp), ('wout', c_vp), ('bout', c_vp), ('ld_wout', c_i64),
                 ('x', c_vp), ('gi', c_vp), ('gh', c_vp), ('logits', c_vp), ('ld_logits', c_i64),
-                ('layers', ctypes.POINTER(TstGruLayer)), ('ht', c_vp), ('ld_ht', c_i64)]
+                ('layers', ctypes.POINTER(TstGruLayer)), ('ht', c_vp), ('ld_ht', c_i64), ('gi_tab', c_vp), ('ld_gi_tab', c_i64)]
 
 
 class TstSelectStep(ctypes.Structure):
@@ -101,6 +101,8 @@ _PROTOS = {
     'tst_attn_cross_mfma_f32': ([c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_gru_cell_step_f32': ([c_vp, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_gru_cell_fused_ok': ([c_i64, c_i64], c_int),
+    'tst_gru_cell_fused_tab_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_vp], c_int),
+    'tst_gru_cell_step_tab_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_i64, c_i64, c_vp], c_int),
     'tst_gru_cell_fused_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_i64, c_i64, c_i64, c_vp], c_int),
     'tst_gru_cell_fused_t_f32': ([c_vp, c_i64, c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_vp, c_i64, c_vp, c_i64, c_i64, c_i64, c_i64,
                                   c_vp], c_int),

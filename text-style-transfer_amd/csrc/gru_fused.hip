@@ -92,16 +92,23 @@ __device__ __forceinline__ void gate_products(const float* __restrict__ A, int64
     }
 }
 
+// TAB: the input product is not computed but READ: gi[row][:] = GiTab[tok[row]][:], a table with one row per vocabulary entry that
+// holds bias_ih + embedding[v] * Wih (made once per model by tst_gemm_mfma_f32 over the embedding matrix: the same fma chain per
+// element, so the same bits).  A decoder whose layer-0 input is a plain embedding lookup then runs half the matrix work per
+// step.  The lane's table values are requested before the recurrent product and arrive under it (they take the registers that
+// the gi accumulators would have).
 // OUT_T: the products are computed transposed (operands swapped: the same fma chain per element), so that a lane owns a ROW
 // of the tile and its 16 registers are 16 columns (4 groups of 4 consecutive ones): the new state goes out as 16-byte pieces
 // of rows AND a second time k-major, HoutT[column][row] (32 lanes = 128 contiguous bytes), the operand layout of the LDS-DMA
 // GEMM that multiplies it with the output projection.
-template <bool OUT_T>
+template <bool OUT_T, bool TAB>
 __global__ __launch_bounds__(256, 2) void gru_fused_kernel(const float* __restrict__ X, int64_t ldx, int E, const float* __restrict__ Hin,
                                                            int64_t ldh, int H, const float* __restrict__ Wih, int64_t ldwi,
                                                            const float* __restrict__ bih, const float* __restrict__ Whh, int64_t ldwh,
                                                            const float* __restrict__ bhh, float* __restrict__ Hout, int64_t ldo,
-                                                           float* __restrict__ HoutT, int64_t ldt, int M, int tiles_m, int tiles_n) {
+                                                           float* __restrict__ HoutT, int64_t ldt, int M, int tiles_m, int tiles_n,
+                                                           const int32_t* __restrict__ tok, int V) {
+    // TAB: X is the table [V][ldx >= 3 H], E is unused, Wih / bih are not read
     __shared__ __attribute__((aligned(16))) GruSmem sm;
     // workgroup id -> tile: every XCD walks a contiguous, m-grouped range of tiles (as gemm_f32_kernel)
     const int nwg = tiles_m * tiles_n;
@@ -124,16 +131,32 @@ __global__ __launch_bounds__(256, 2) void gru_fused_kernel(const float* __restri
         for (int g = 0; g < 3; ++g)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const float4 bi = bih != nullptr ? *reinterpret_cast<const float4*>(bih + g * H + cbase + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 bi = (!TAB && bih != nullptr) ? *reinterpret_cast<const float4*>(bih + g * H + cbase + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
                 const float4 bh = bhh != nullptr ? *reinterpret_cast<const float4*>(bhh + g * H + cbase + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    gi[i][g][4 * q] = bi.x; gi[i][g][4 * q + 1] = bi.y; gi[i][g][4 * q + 2] = bi.z; gi[i][g][4 * q + 3] = bi.w;
+                    if (!TAB) { gi[i][g][4 * q] = bi.x; gi[i][g][4 * q + 1] = bi.y; gi[i][g][4 * q + 2] = bi.z; gi[i][g][4 * q + 3] = bi.w; }
                     gh[i][g][4 * q] = bh.x; gh[i][g][4 * q + 1] = bh.y; gh[i][g][4 * q + 2] = bh.z; gh[i][g][4 * q + 3] = bh.w;
                 }
             }
-        gate_products<true>(X, ldx, Wih, ldwi, E, H, M, m0, n0, gi, sm);
-        __syncthreads();
+        if (TAB) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = min(m0 + wm * 64 + i * 32 + (lane & 31), M - 1);
+                const int id = min(max(tok[row], 0), V - 1);
+                const float* tp = X + (int64_t)id * ldx + cbase;
+#pragma unroll
+                for (int g = 0; g < 3; ++g)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float4 v = *reinterpret_cast<const float4*>(tp + g * H + 8 * q);
+                        gi[i][g][4 * q] = v.x; gi[i][g][4 * q + 1] = v.y; gi[i][g][4 * q + 2] = v.z; gi[i][g][4 * q + 3] = v.w;
+                    }
+            }
+        } else {
+            gate_products<true>(X, ldx, Wih, ldwi, E, H, M, m0, n0, gi, sm);
+            __syncthreads();
+        }
         gate_products<true>(Hin, ldh, Whh, ldwh, H, H, M, m0, n0, gh, sm);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -154,8 +177,10 @@ __global__ __launch_bounds__(256, 2) void gru_fused_kernel(const float* __restri
                                gh[i][2][4 * q + 3], hv[q].w);
                 if (row < M) {
                     *reinterpret_cast<float4*>(Hout + (int64_t)row * ldo + cbase + 8 * q) = o;
-                    float* tp = HoutT + (int64_t)(cbase + 8 * q) * ldt + row;
-                    tp[0] = o.x; tp[ldt] = o.y; tp[2 * ldt] = o.z; tp[3 * ldt] = o.w;
+                    if (HoutT != nullptr) {   // (always set without TAB)
+                        float* tp = HoutT + (int64_t)(cbase + 8 * q) * ldt + row;
+                        tp[0] = o.x; tp[ldt] = o.y; tp[2 * ldt] = o.z; tp[3 * ldt] = o.w;
+                    }
                 }
             }
         }
@@ -171,6 +196,7 @@ __global__ __launch_bounds__(256, 2) void gru_fused_kernel(const float* __restri
 #pragma unroll
             for (int r = 0; r < 16; ++r) { gi[i][g][r] = bi; gh[i][g][r] = bh; }
     }
+    static_assert(OUT_T || !TAB, "the table form exists in the row-per-lane layout only (16-byte table reads)");
     gate_products<false>(X, ldx, Wih, ldwi, E, H, M, m0, n0, gi, sm);
     __syncthreads();      // every wave has read its last operands before the images are overwritten
     gate_products<false>(Hin, ldh, Whh, ldwh, H, H, M, m0, n0, gh, sm);
@@ -227,15 +253,47 @@ int gru_cell_fused_impl(const char* who, const float* x, int64_t ldx, const floa
     const int64_t tiles_m = (R + BM - 1) / BM, tiles_n = H / BN;
     TST_REQUIRE(tiles_m * tiles_n < (1ll << 31), TST_ERR_UNSUPPORTED, "%s: grid too large", who);
     if (h_out_t != nullptr)
-        hipLaunchKernelGGL(gru_fused_kernel<true>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)E, h,
-                           ldh, (int)H, wih, ld_wih, bih, whh, ld_whh, bhh, h_out, ldo, h_out_t, ldt, (int)R, (int)tiles_m, (int)tiles_n);
+        hipLaunchKernelGGL((gru_fused_kernel<true, false>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)E, h,
+                           ldh, (int)H, wih, ld_wih, bih, whh, ld_whh, bhh, h_out, ldo, h_out_t, ldt, (int)R, (int)tiles_m, (int)tiles_n,
+                           (const int32_t*)nullptr, 0);
     else
-        hipLaunchKernelGGL(gru_fused_kernel<false>, dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)E, h,
-                           ldh, (int)H, wih, ld_wih, bih, whh, ld_whh, bhh, h_out, ldo, nullptr, 0, (int)R, (int)tiles_m, (int)tiles_n);
+        hipLaunchKernelGGL((gru_fused_kernel<false, false>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, (hipStream_t)stream, x, ldx, (int)E, h,
+                           ldh, (int)H, wih, ld_wih, bih, whh, ld_whh, bhh, h_out, ldo, (float*)nullptr, (int64_t)0, (int)R, (int)tiles_m,
+                           (int)tiles_n, (const int32_t*)nullptr, 0);
     return tst_after_launch(who);
 }
 
 }  // namespace
+
+extern "C" int tst_gru_cell_fused_tab_f32(const float* gi_tab, int64_t ld_tab, const int32_t* tok, int64_t V, const float* h, int64_t ldh,
+                                          const float* whh, int64_t ld_whh, const float* bhh, float* h_out, int64_t ldo, float* h_out_t,
+                                          int64_t ldt, int64_t R, int64_t H, void* stream) {
+    const char* who = "tst_gru_cell_fused_tab_f32";
+    TST_REQUIRE(gi_tab && tok && h && whh && h_out, TST_ERR_ARG, "%s: null pointer", who);
+    TST_REQUIRE(R >= 0 && R < (1ll << 31) && H > 0 && V > 0 && V < (1ll << 31), TST_ERR_ARG, "%s: bad sizes", who);
+    TST_REQUIRE(H >= BN && H % BN == 0, TST_ERR_UNSUPPORTED, "%s: needs H %% 64 == 0 (got %lld)", who, (long long)H);
+    TST_REQUIRE(ld_tab >= 3 * H && ldh >= H && ldo >= H && ld_whh >= 3 * H && ld_tab % 4 == 0 && ldh % 4 == 0 && ld_whh % 4 == 0, TST_ERR_ARG,
+                "%s: leading dimensions (multiples of 4, at least the row length)", who);
+    TST_REQUIRE(tst_aligned16(gi_tab) && tst_aligned16(h) && tst_aligned16(whh), TST_ERR_ARG, "%s: gi_tab, h, whh must be 16-byte aligned", who);
+    const char *hb = (const char*)h, *ob = (const char*)h_out;
+    const int64_t hbytes = (R > 0 ? ((R - 1) * ldh + H) : 0) * 4, obytes = (R > 0 ? ((R - 1) * ldo + H) : 0) * 4;
+    TST_REQUIRE(ob + obytes <= hb || hb + hbytes <= ob, TST_ERR_ARG, "%s: h_out must not overlap h", who);
+    TST_REQUIRE(ldo % 4 == 0 && tst_aligned16(h_out) && tst_aligned16(bhh), TST_ERR_ARG, "%s: ldo %% 4 == 0 and 16-byte aligned h_out, bhh", who);
+    if (h_out_t != nullptr) {
+        TST_REQUIRE(ldt >= R, TST_ERR_ARG, "%s: the k-major copy needs ldt >= R", who);
+        const char* tb = (const char*)h_out_t;
+        const int64_t tbytes = (R > 0 ? ((H - 1) * ldt + R) : 0) * 4;
+        TST_REQUIRE(tb + tbytes <= hb || hb + hbytes <= tb, TST_ERR_ARG, "%s: h_out_t must not overlap h", who);
+    }
+    if (R == 0) return TST_OK;
+    const int64_t tiles_m = (R + BM - 1) / BM, tiles_n = H / BN;
+    TST_REQUIRE(tiles_m * tiles_n < (1ll << 31), TST_ERR_UNSUPPORTED, "%s: grid too large", who);
+    // the row-per-lane layout whether or not the k-major copy is wanted (h_out_t may be NULL)
+    hipLaunchKernelGGL((gru_fused_kernel<true, true>), dim3((unsigned)(tiles_m * tiles_n)), dim3(256), 0, (hipStream_t)stream, gi_tab, ld_tab,
+                       0, h, ldh, (int)H, (const float*)nullptr, (int64_t)0, (const float*)nullptr, whh, ld_whh, bhh, h_out, ldo, h_out_t, ldt,
+                       (int)R, (int)tiles_m, (int)tiles_n, tok, (int)V);
+    return tst_after_launch(who);
+}
 
 extern "C" int tst_gru_cell_fused_f32(const float* x, int64_t ldx, const float* h, int64_t ldh, const float* wih, int64_t ld_wih,
                                       const float* bih, const float* whh, int64_t ld_whh, const float* bhh, float* h_out,

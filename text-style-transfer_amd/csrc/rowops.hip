@@ -149,14 +149,17 @@ void launch_layernorm(const float* x, const float* gamma, const float* beta, flo
     else hipLaunchKernelGGL(layernorm_kernel<TO>, grid, block, 0, st, x, gamma, beta, eps, y, R, (int)(d / 4));
 }
 
-// one thread per float4 of h
+// one thread per float4 of h.  gi_row (when not NULL): row r takes its input pre-activations from row gi_row[r] (clamped to
+// 0 .. V - 1) of gi, a table with one row per vocabulary entry (ldgi4 float4 per row), instead of row r
 __global__ __launch_bounds__(256) void gru_cell_kernel(const float* __restrict__ gi, const float* __restrict__ gh,
-                                                       const float* h, float* h_out, int64_t R, int H4) {
+                                                       const float* h, float* h_out, int64_t R, int H4,
+                                                       const int32_t* __restrict__ gi_row = nullptr, int V = 0, int64_t ldgi4 = 0) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= R * H4) return;
     const int64_t r = i / H4;
     const int c4 = (int)(i - r * H4);
-    const float4* a = reinterpret_cast<const float4*>(gi) + r * 3 * H4;
+    const float4* a = gi_row != nullptr ? reinterpret_cast<const float4*>(gi) + (int64_t)min(max(gi_row[r], 0), V - 1) * ldgi4
+                                        : reinterpret_cast<const float4*>(gi) + r * 3 * H4;
     const float4* b = reinterpret_cast<const float4*>(gh) + r * 3 * H4;
     const float4 ir = a[c4], iz = a[H4 + c4], in = a[2 * H4 + c4];
     const float4 hr = b[c4], hz = b[H4 + c4], hn = b[2 * H4 + c4];
@@ -353,6 +356,19 @@ extern "C" int tst_add_rows_f32(float* x, const float* z, const int32_t* idx, in
     hipLaunchKernelGGL(add_rows_kernel, dim3(blocks_for(R * (d / 4), 256)), dim3(256), 0, (hipStream_t)stream, x, z, idx, R,
                        (int)(d / 4));
     return tst_after_launch("tst_add_rows_f32");
+}
+
+extern "C" int tst_gru_cell_step_tab_f32(const float* gi_tab, int64_t ld_tab, const int32_t* tok, int64_t V, const float* gh, const float* h,
+                                         float* h_out, int64_t R, int64_t H, void* stream) {
+    TST_REQUIRE(gi_tab && tok && gh && h && h_out, TST_ERR_ARG, "tst_gru_cell_step_tab_f32: null pointer");
+    TST_REQUIRE(R >= 0 && H > 0 && H % 4 == 0 && V > 0 && V < (1ll << 31) && ld_tab >= 3 * H && ld_tab % 4 == 0, TST_ERR_ARG,
+                "tst_gru_cell_step_tab_f32: need H %% 4 == 0, V > 0, ld_tab %% 4 == 0, ld_tab >= 3 H");
+    TST_REQUIRE(tst_aligned16(gi_tab) && tst_aligned16(gh) && tst_aligned16(h) && tst_aligned16(h_out), TST_ERR_ARG,
+                "tst_gru_cell_step_tab_f32: alignment");
+    if (R == 0) return TST_OK;
+    hipLaunchKernelGGL(gru_cell_kernel, dim3(blocks_for(R * (H / 4), 256)), dim3(256), 0, (hipStream_t)stream, gi_tab, gh, h, h_out, R,
+                       (int)(H / 4), tok, (int)V, ld_tab / 4);
+    return tst_after_launch("tst_gru_cell_step_tab_f32");
 }
 
 extern "C" int tst_gru_cell_step_f32(const float* gi, const float* gh, const float* h, float* h_out, int64_t R, int64_t H,

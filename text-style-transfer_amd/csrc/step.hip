@@ -216,8 +216,13 @@ extern "C" int tst_gru_step_run(const tst_gru_step* m, const int32_t* tok, const
     TST_REQUIRE(!fused || tst_gru_cell_fused_ok(m->E, m->H), TST_ERR_UNSUPPORTED,
                 "tst_gru_step_run: TST_STEP_FUSED_CELL needs E %% 16 == 0 and H %% 64 == 0");
     TST_REQUIRE(m->x && m->logits && (fused || (m->gi && m->gh)), TST_ERR_ARG, "tst_gru_step_run: null work buffer");
+    TST_REQUIRE(!fused || m->gi_tab == nullptr || m->H % 64 == 0, TST_ERR_UNSUPPORTED, "tst_gru_step_run: gi_tab with TST_STEP_FUSED_CELL needs H %% 64 == 0");
     if (R == 0) return TST_OK;
-    if (phases & TST_STEP_EMBED) {
+    // layer 0 reads its input pre-activations from the per-token table instead of multiplying the embeddings (which are then
+    // not needed at all): token inputs, no per-sentence vector added to them
+    const bool use_tab = m->gi_tab != nullptr && (phases & TST_STEP_EMBED) && (phases & TST_STEP_LAYERS) && m->extra == nullptr;
+    TST_REQUIRE(!use_tab || (tok != nullptr && m->ld_gi_tab >= 3 * (int64_t)m->H), TST_ERR_ARG, "tst_gru_step_run: gi_tab needs tok and ld_gi_tab >= 3 H");
+    if ((phases & TST_STEP_EMBED) && !use_tab) {
         TST_REQUIRE(tok && m->emb, TST_ERR_ARG, "tst_gru_step_run: null embedding input");
         TST_TRY(tst_embed_posadd_f32(tok, m->emb, nullptr, nullptr, 1.0f, m->x, R, m->E, m->V, stream));
     }
@@ -241,7 +246,11 @@ extern "C" int tst_gru_step_run(const tst_gru_step* m, const int32_t* tok, const
             TST_REQUIRE(L.wih && L.whh && L.h, TST_ERR_ARG, "tst_gru_step_run: layer %d incomplete", l);
             if (fused) {
                 TST_REQUIRE(L.h_alt != nullptr, TST_ERR_ARG, "tst_gru_step_run: layer %d has no h_alt", l);
-                if (dma_vocab && l == m->n_layers - 1)
+                if (use_tab && l == 0) {
+                    const bool kmajor = dma_vocab && m->n_layers == 1;
+                    TST_TRY(tst_gru_cell_fused_tab_f32(m->gi_tab, m->ld_gi_tab, tok, m->V, L.h, m->H, L.whh, L.ld_whh, L.bhh, L.h_alt, m->H,
+                                                       kmajor ? m->ht : nullptr, kmajor ? m->ld_ht : 0, R, m->H, stream));
+                } else if (dma_vocab && l == m->n_layers - 1)
                     TST_TRY(tst_gru_cell_fused_t_f32(x, in, L.h, m->H, L.wih, L.ld_wih, L.bih, L.whh, L.ld_whh, L.bhh, L.h_alt, m->H, m->ht,
                                                      m->ld_ht, R, in, m->H, stream));
                 else
@@ -251,9 +260,11 @@ extern "C" int tst_gru_step_run(const tst_gru_step* m, const int32_t* tok, const
                 in = m->H;
                 continue;
             }
-            TST_TRY(tst_gemm_mfma_f32(x, in, L.wih, L.ld_wih, L.bih, nullptr, 0, m->gi, 3 * m->H, R, 3 * m->H, in, 0, stream));
+            if (!(use_tab && l == 0))
+                TST_TRY(tst_gemm_mfma_f32(x, in, L.wih, L.ld_wih, L.bih, nullptr, 0, m->gi, 3 * m->H, R, 3 * m->H, in, 0, stream));
             TST_TRY(tst_gemm_mfma_f32(L.h, m->H, L.whh, L.ld_whh, L.bhh, nullptr, 0, m->gh, 3 * m->H, R, 3 * m->H, m->H, 0, stream));
-            TST_TRY(tst_gru_cell_step_f32(m->gi, m->gh, L.h, L.h, R, m->H, stream));
+            if (use_tab && l == 0) TST_TRY(tst_gru_cell_step_tab_f32(m->gi_tab, m->ld_gi_tab, tok, m->V, m->gh, L.h, L.h, R, m->H, stream));
+            else TST_TRY(tst_gru_cell_step_f32(m->gi, m->gh, L.h, L.h, R, m->H, stream));
             x = L.h;
             in = m->H;
         }

@@ -314,6 +314,40 @@ def gru_cell_fused_t(x, h, wih, bih, whh, bhh, h_out, h_out_t, n_rows):
          _p(bhh), _p(h_out), h_out.stride(0), _p(h_out_t), h_out_t.stride(0), n_rows, E, H, _stream())
 
 
+def gru_cell_fused_tab(gi_tab, tok, h, whh, bhh, h_out, n_rows, h_out_t=None):
+    """``gru_cell_fused`` for inputs that are embedding lookups: the input pre-activations of row r are row ``tok[r]`` of
+    ``gi_tab`` [V, 3H] (= bias_ih + embedding @ wih, see ``gi_table``) instead of a product computed here."""
+    for t, nm in ((gi_tab, 'gi_tab'), (h, 'h'), (whh, 'whh'), (h_out, 'h_out'), (bhh, 'bhh'), (h_out_t, 'h_out_t')):
+        if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.stride(-1) == 1):
+            raise ValueError('%s must be an fp32 GPU tensor with unit inner stride' % nm)
+    _chk(tok, torch.int32, 'tok')
+    H = whh.shape[0]
+    assert gi_tab.shape[1] >= 3 * H and h.shape[1] == H and h_out.shape[1] == H and min(tok.numel(), h.shape[0], h_out.shape[0]) >= n_rows
+    assert h_out_t is None or (h_out_t.shape[0] == H and h_out_t.shape[1] >= n_rows)
+    call('tst_gru_cell_fused_tab_f32', _p(gi_tab), gi_tab.stride(0), _p(tok), gi_tab.shape[0], _p(h), h.stride(0), _p(whh), whh.stride(0),
+         _p(bhh), _p(h_out), h_out.stride(0), _p(h_out_t), 0 if h_out_t is None else h_out_t.stride(0), n_rows, H, _stream())
+
+
+def gru_cell_step_tab(gi_tab, tok, gh, h, h_out, n_rows):
+    """``gru_cell_step`` with the input pre-activations of row r taken from row ``tok[r]`` of ``gi_tab`` [V, 3H]."""
+    if not (gi_tab.is_cuda and gi_tab.dtype == torch.float32 and gi_tab.stride(-1) == 1):
+        raise ValueError('gi_tab must be an fp32 GPU tensor with unit inner stride')
+    _chk(gh, torch.float32, 'gh'); _chk(h, torch.float32, 'h'); _chk(h_out, torch.float32, 'h_out')
+    _chk(tok, torch.int32, 'tok')
+    H = h.shape[1]
+    assert gi_tab.shape[1] >= 3 * H and gh.shape[1] == 3 * H and h_out.shape[1] == H
+    call('tst_gru_cell_step_tab_f32', _p(gi_tab), gi_tab.stride(0), _p(tok), gi_tab.shape[0], _p(gh), _p(h), _p(h_out), n_rows, H, _stream())
+
+
+def gi_table(emb, wih, bih):
+    """[V, 3H] = bias_ih + emb @ wih: the input pre-activations of a GRU layer for every vocabulary entry, by the same product
+    kernel (hence the same fma chain per element) that a step would run on the looked-up embeddings."""
+    V = emb.shape[0]
+    out = torch.empty((V, wih.shape[1]), dtype=torch.float32, device=emb.device)
+    gemm(emb, wih, bih, out, V)
+    return out
+
+
 def gather_rows(src, idx, dst, n_rows):
     _chk(src, torch.float32, 'src'); _chk(dst, torch.float32, 'dst'); _chk(idx, torch.int32, 'idx')
     assert src.shape[1] == dst.shape[1]
@@ -442,8 +476,8 @@ class GruPlan:
     ``wih, bih, whh, bhh``; ``h`` / ``h_alt`` are the session's lists of state buffers, which ``swap()`` exchanges
     after a reorder."""
 
-    def __init__(self, *, E, H, V, rows, emb, extra, cells, h, h_alt, wout, bout, x, gi, gh, logits, ht=None):
-        self._keep = [emb, extra, cells, h, h_alt, wout, bout, x, gi, gh, logits, ht]
+    def __init__(self, *, E, H, V, rows, emb, extra, cells, h, h_alt, wout, bout, x, gi, gh, logits, ht=None, gi_tab=None):
+        self._keep = [emb, extra, cells, h, h_alt, wout, bout, x, gi, gh, logits, ht, gi_tab]
         n = len(cells)
         self._layers = (_lib.TstGruLayer * n)()
         for dst, c, a, b in zip(self._layers, cells, h, h_alt):
@@ -452,7 +486,8 @@ class GruPlan:
             dst.h, dst.h_alt = _p(a), _p(b)
         self.c = _lib.TstGruStep(n_layers=n, E=E, H=H, V=V, rows=rows, emb=_p(emb), extra=_p(extra), wout=_p(wout), bout=_p(bout),
                                  ld_wout=wout.stride(0), x=_p(x), gi=_p(gi), gh=_p(gh), logits=_p(logits),
-                                 ld_logits=logits.stride(0), layers=self._layers, ht=_p(ht), ld_ht=0 if ht is None else ht.stride(0))
+                                 ld_logits=logits.stride(0), layers=self._layers, ht=_p(ht), ld_ht=0 if ht is None else ht.stride(0),
+                                 gi_tab=_p(gi_tab), ld_gi_tab=0 if gi_tab is None else gi_tab.stride(0))
 
     def run(self, rows, n_rows, phases):
         """With ``STEP_FUSED_CELL`` in ``phases`` (and the layers run) the new state of every layer lands in ``h_alt``: the

@@ -56,6 +56,17 @@ class _GRUModel(HipModule):
             W['emb_pad'] = _pad_rows4(W['emb'])
         return W['emb_pad']
 
+    def gi_table(self):
+        """[V, 3H]: layer 0's input pre-activations (bias_ih + embedding @ W_ih) of every vocabulary entry, made once per
+        set of weights, or None when it would not pay (see ``GI_TABLE_MAX_BYTES``).  A decode step whose inputs are token ids
+        then looks the rows up instead of multiplying the embeddings: same values (the same product kernel made them)."""
+        W = self.prepared()
+        if 'gi_tab' not in W:
+            nbytes = self.V * 3 * self.H * 4
+            W['gi_tab'] = (K.gi_table(W['emb'], W['cells'][0]['wih'], W['cells'][0]['bih'])
+                           if GI_TABLE_MAX_BYTES > 0 and nbytes <= GI_TABLE_MAX_BYTES else None)
+        return W['gi_tab']
+
     def session(self, z, enc_mask=None, rows_per_sentence=1, max_len=None):
         return GRUSession(self, z, rows_per_sentence)
 
@@ -154,9 +165,16 @@ class ConditionalLM(_GRUModel):
         return (logits, z_new) if return_z else logits
 
 
+# Largest table of per-token input pre-activations a model may keep (bytes; V * 3H floats: 1.5 MB for a character vocabulary,
+# 393 MB for 32000 tokens at H = 1024); TST_NO_GI_TABLE=1 in the environment turns the tables off (measurements; same results)
+GI_TABLE_MAX_BYTES = 0 if os.environ.get('TST_NO_GI_TABLE') else 2 << 30
+
 # rows from which the one-kernel GRU cell is used: below, 128 x 64 tiles leave most compute units without work and the
 # small-problem GEMM kernels of the three-call form are faster
 FUSED_MIN_ROWS = int(os.environ.get('TST_GRU_FUSED_MIN_ROWS', '2048'))   # measured crossover at E = H = 1024: between 1024 and 2048 rows
+# the same when layer 0 reads its input pre-activations from the per-token table (half the work in either form): the two forms
+# are within 2 % of each other from 1 k rows on, the three-call form 3-5 % ahead between 2 k and 4 k rows (measured)
+FUSED_MIN_ROWS_TAB = int(os.environ.get('TST_GRU_FUSED_MIN_ROWS', '4096'))
 
 
 class GRUSession:
@@ -199,9 +217,11 @@ class GRUSession:
     def _plan(self):
         if self.plan is None:
             m, W = self.m, self.m.prepared()
+            # token inputs without a per-sentence vector added to them: layer 0 looks its input pre-activations up per token
+            gi_tab = m.gi_table() if self.extra is None else None
             self.plan = K.GruPlan(E=m.E, H=m.H, V=m.V, rows=self.R, emb=W['emb'], extra=self.extra, cells=W['cells'], h=self.h,
                                   h_alt=self.h_alt, wout=W['wout'], bout=W['bout'], x=self.x, gi=self.gi, gh=self.gh, logits=self.logits,
-                                  ht=self.ht)
+                                  ht=self.ht, gi_tab=gi_tab)
         return self.plan
 
     def reorder(self, row_parent, n_rows, identity):
@@ -219,10 +239,12 @@ class GRUSession:
             K.soft_embed(soft, self.m.soft_embedding_matrix(), 1.0, None, self.x, n)
         # from FUSED_MIN_ROWS rows on every layer's cell is one kernel (gate pre-activations stay in the matrix-core accumulators);
         # it writes the new state to the other buffer of the pair
-        fused = n >= FUSED_MIN_ROWS and K.gru_cell_fused_ok(self.m.E, self.m.H)
+        plan = self._plan()
+        tab = plan.c.gi_tab is not None and soft is None
+        fused = n >= (FUSED_MIN_ROWS_TAB if tab else FUSED_MIN_ROWS) and K.gru_cell_fused_ok(self.m.E, self.m.H)
         if fused:
             phases |= K.STEP_FUSED_CELL
-        self._plan().run(rows, n, phases)
+        plan.run(rows, n, phases)
         if fused:
             self.h, self.h_alt = self.h_alt, self.h
         return self.logits
