@@ -1,5 +1,5 @@
 #!/bin/bash
-# r03_ak: records on the final tree (ABI 107): GPU suite, smoke, default bench line, rocprofv3 profile set of the bench command,
+# r03_ak: records on the final tree (ABI 108): GPU suite, smoke, default bench line, rocprofv3 profile set of the bench command,
 # config 1 / 4 lines
 set -o pipefail
 mkdir -p gpurun_out
