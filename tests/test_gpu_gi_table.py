@@ -88,6 +88,32 @@ def test_ids_outside_the_vocabulary_are_clamped_like_the_embedding_lookup(K):
         K.gru_cell_fused_tab(tab, tok, h, wh, None, h, R)
 
 
+def test_encoder_with_the_table_equals_embedding_product_and_update(K):
+    """RNNEncoder looks the input pre-activations of every position up in its table; the same pass spelled out with the
+    embedding kernel, one input product over all positions and the plain update kernel gives the same final states."""
+    import tst_amd
+    from tst_amd import synthetic
+    vocab = tst_amd.Vocab.synthetic(90)
+    enc = tst_amd.RNNEncoder(64, 128, vocab)
+    enc.load_state_dict(synthetic.synthetic_state_dict(enc, seed=4))
+    B, T = 37, 9
+    x = torch.randint(0, 90, (B, T), generator=torch.Generator().manual_seed(8)).cuda()
+    z = enc(x)
+    W = enc.prepared()
+    assert W['gi_tab'] is not None
+    tok = x.to(torch.int32).t().contiguous().view(-1)
+    emb = torch.empty((T * B, 64), device='cuda')
+    K.embed_posadd(tok, W['emb'], None, 1.0, emb, T * B)
+    gi = torch.empty((T * B, 3 * 128), device='cuda')
+    K.gemm(emb, W['wih'], W['bih'], gi, T * B)
+    h = torch.zeros((B, 128), device='cuda')
+    gh = torch.empty((B, 3 * 128), device='cuda')
+    for t in range(T):
+        K.gemm(h, W['whh'], W['bhh'], gh, B)
+        K.gru_cell_step(gi[t * B:(t + 1) * B], gh, h, h, B)
+    assert torch.equal(z, h)
+
+
 CHILD = r'''
 import hashlib, sys, torch
 sys.path.insert(0, %r)

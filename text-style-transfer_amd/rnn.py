@@ -334,9 +334,11 @@ class EnsembleSession:
 class RNNEncoder(HipModule):
     """``RNNEncoder(emb_size, hid_size, vocab, dropword_p, noise=...)``; ``encoder(x [B, T] ids) -> z [B, H]``, the
     final state of a one-layer GRU started at zero and run over all T positions (padding included, nothing is
-    packed).  Inference only: ``dropword_p`` and ``noise`` act in training and are ignored.  The input products of
-    all positions are one GEMM ([B * T, E] x [E, 3H]); the loop over positions does the recurrent product and the
-    gate update."""
+    packed).  Inference only: ``dropword_p`` and ``noise`` act in training and are ignored.  The input pre-activations
+    of a position are rows of the per-token table (``bias_ih + embedding @ W_ih``, made once per set of weights; see
+    ``_GRUModel.gi_table``) looked up by the gate update kernel; without the table (``TST_NO_GI_TABLE``, or a table beyond
+    ``GI_TABLE_MAX_BYTES``) the input products of all positions are one GEMM ([B * T, E] x [E, 3H]).  The loop over
+    positions does the recurrent product and the gate update.  Same values either way."""
 
     def __init__(self, emb_size, hid_size, vocab, dropword_p=0.0, noise=0.0, device='cuda'):
         super().__init__(device)
@@ -363,15 +365,23 @@ class RNNEncoder(HipModule):
         dev = self.device
         f32 = dict(dtype=torch.float32, device=dev)
         tok = x.to(device=dev, dtype=torch.int32).t().contiguous().view(-1)      # position-major: rows t * B + b
-        emb = torch.empty((T * B, self.E), **f32)
-        K.embed_posadd(tok, W['emb'], None, 1.0, emb, T * B)
-        gi = torch.empty((T * B, 3 * self.H), **f32)
-        K.gemm(emb, W['wih'], W['bih'], gi, T * B)
+        if 'gi_tab' not in W:
+            nbytes = self.V * 3 * self.H * 4
+            W['gi_tab'] = K.gi_table(W['emb'], W['wih'], W['bih']) if 0 < nbytes <= GI_TABLE_MAX_BYTES else None
+        tab = W['gi_tab']
+        if tab is None:
+            emb = torch.empty((T * B, self.E), **f32)
+            K.embed_posadd(tok, W['emb'], None, 1.0, emb, T * B)
+            gi = torch.empty((T * B, 3 * self.H), **f32)
+            K.gemm(emb, W['wih'], W['bih'], gi, T * B)
         h = torch.zeros((B, self.H), **f32)
         gh = torch.empty((B, 3 * self.H), **f32)
         for t in range(T):
             K.gemm(h, W['whh'], W['bhh'], gh, B)
-            K.gru_cell_step(gi[t * B:(t + 1) * B], gh, h, h, B)
+            if tab is None:
+                K.gru_cell_step(gi[t * B:(t + 1) * B], gh, h, h, B)
+            else:
+                K.gru_cell_step_tab(tab, tok[t * B:(t + 1) * B], gh, h, h, B)
         return h
 
 
