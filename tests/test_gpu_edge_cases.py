@@ -177,6 +177,41 @@ def test_loop_without_per_step_count_read_equals_exact_loop(T, beam):
         engine.LAG_MAX_ROWS = old
 
 
+def test_greedy_tail_switches_prefixes_and_kept_logits(T):
+    """Greedy steps that end in arg-max keys (no logits) and the survivor count written to host memory by the tail kernel,
+    against the loop with logits, a separate arg-max and a queued copy, in every combination; with a prefix of several
+    tokens (fed step by step before the loop) and with the logits of the first steps kept (those steps must write logits):
+    always the oracle's sequences."""
+    from tst_amd import engine
+    tmodel, model, vocab, encs, mask = mt_case(T, 300, 41, 9, 2.0, 77)
+    want = oracle(tmodel, encs, mask, 14, 1)[0]
+    old = (engine.KEYS_ON, engine.HOST_COUNT_ON, engine.LAG_MAX_ROWS)
+    try:
+        for keys_on in (True, False):
+            for host_on in (True, False):
+                for lag in (0, 1 << 20):
+                    engine.KEYS_ON, engine.HOST_COUNT_ON, engine.LAG_MAX_ROWS = keys_on, host_on, lag
+                    got, st = decode(T, model, vocab, encs, mask, 14, 1)
+                    assert got == want
+                    assert (st.loop.keys is not None) == keys_on
+        engine.KEYS_ON, engine.HOST_COUNT_ON, engine.LAG_MAX_ROWS = True, True, 1 << 20
+        st = T.InferenceState({'model': model.decoder, 'inputs': torch.from_numpy(encs).cuda(), 'enc_mask': torch.from_numpy(mask).cuda(),
+                               'vocab': vocab, 'max_len': 14})
+        kept = [s.cpu().tolist() for s in st.inference(keep_logits=3)]
+        assert kept == want and len(st.loop.kept) == 3 and st.loop.keys is not None
+        # a prefix: the first three tokens of every oracle sequence (padded with the sequence's own continuation)
+        outs = []
+        for keys_on in (True, False):
+            engine.KEYS_ON = keys_on
+            prefix = torch.tensor([[2, 5 + (i % 7), 9 + (i % 5)] for i in range(41)])
+            st = T.InferenceState({'model': model.decoder, 'inputs': torch.from_numpy(encs).cuda(), 'enc_mask': torch.from_numpy(mask).cuda(),
+                                   'vocab': vocab, 'max_len': 10, 'active_seqs': prefix})
+            outs.append([s.cpu().tolist() for s in st.inference()])
+        assert outs[0] == outs[1] and all(o[:3] == [2, 5 + (i % 7), 9 + (i % 5)] for i, o in enumerate(outs[0]))
+    finally:
+        engine.KEYS_ON, engine.HOST_COUNT_ON, engine.LAG_MAX_ROWS = old
+
+
 @pytest.mark.parametrize('beam', [1, 4])
 def test_concurrent_batches_on_streams_of_their_own_equal_sequential_decodes(T, beam):
     """Independent batches decoded at the same time, one host thread and one HIP stream each over ONE model object, give the
