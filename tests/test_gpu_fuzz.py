@@ -1,4 +1,5 @@
-"""Seeded random configurations of the transformer decode path (model sizes, head counts, vocabulary, batch, source lengths,
+"""Seeded random configurations of the decode paths (transformer from cached encoder outputs and from source ids, GRU decoder,
+transformer LM, stateful GRU LMs) (model sizes, head counts, vocabulary, batch, source lengths,
 beam, length penalty, max_len) against the canonical oracle, bit for bit: tokens, hypothesis scores and output lengths.
 The cases are drawn to reach what the fixed-size tests do not: one-sentence and one-position batches, heads of 8 to 128
 elements, beams wider than the vocabulary's live mass, max_len of 1, sentences that never end, batches that all end at once,
@@ -152,3 +153,78 @@ def test_random_gemm_shapes_bit_exact(seed):
     got = out.cpu().numpy()
     assert np.array_equal(got[:, :N], C.gemm(A, W, b, R0, act)), (M, N, Kd, bias, act, res)
     assert (got[:, N:] == 7.0).all()
+
+
+@pytest.mark.parametrize('seed', seeds(10))
+def test_random_transformer_lm(T, seed):
+    """z-conditioned TransformerLM (lm_trainer.py:72-74,86) in fp32 at random sizes, greedy and beam with and without a
+    length penalty: tokens and scores bit for bit."""
+    r = np.random.RandomState(4000 + seed)
+    heads = int(r.choice([1, 2, 4, 8]))
+    d = heads * int(r.choice([8, 16, 32, 64]))
+    max_len = int(r.choice([1, 3, 12, 30]))
+    hp = dict(model_size=d, n_layers=int(r.choice([1, 2, 4])), n_heads=heads, d_ff=int(r.choice([32, 128, 512])), pe_max_len=max_len + 2)
+    V, B = int(r.choice([12, 90, 700, 3000])), int(r.choice([1, 4, 50, 260]))
+    beam, alpha = int(r.choice([1, 1, 3, 8])), float(r.choice([0.0, 0.7]))
+    tv = R.synthetic_vocab(V)
+    tmodel = R.synthetic_init(R.TransformerLM(R.HP(hp), tv), 3, float(r.choice([0.0, 2.0, 5.0])), 2.0, seed=seed)
+    vocab = T.Vocab.synthetic(V)
+    lm = T.TransformerLM(T.HP(hp), vocab, dtype='fp32')
+    lm.load_state_dict(tmodel.state_dict())
+    z = (0.3 * r.standard_normal((B, d))).astype(np.float32)
+    st = T.InferenceState({'model': lm, 'inputs': torch.from_numpy(z).cuda(), 'vocab': vocab, 'max_len': max_len,
+                           'beam_size': beam, 'length_penalty': alpha})
+    out = [s.cpu().tolist() for s in st.inference()]
+    sess = C.CanonTransformerLM(tmodel).session(z, beam, max_len)
+    if beam == 1:
+        want = C.greedy_decode(sess, B, max_len, 2, 3)[0]
+    else:
+        want, scores, _, _ = C.beam_decode(sess, B, beam, max_len, 2, 3, alpha)
+        assert np.array_equal(st.scores.cpu().numpy(), scores), (hp, V, B, beam, alpha)
+    assert out == want, (hp, V, B, beam, alpha)
+
+
+@pytest.mark.parametrize('seed', seeds(12))
+def test_random_stateful_gru_lm(T, seed):
+    """RNNLM / ConditionalLM of 1 to 3 layers in the stateful mode of prod/dialog_model.py:108-120 (bos = eos = '|', the carried
+    state substituted for the inputs) at random sizes: arg-max, temperature sampling (draw for draw) and beam search; a
+    ConditionalLM with one style per sentence."""
+    r = np.random.RandomState(5000 + seed)
+    H, layers = int(r.choice([32, 64, 128, 320])), int(r.choice([1, 2, 3]))
+    V, B = int(r.choice([10, 50, 130, 900])), int(r.choice([1, 5, 70, 300, 2200]))
+    max_len = int(r.choice([1, 6, 25]))
+    mode = str(r.choice(['max', 'sample', 'beam']))
+    conditional = bool(r.randint(2)) and layers == 2
+    tv = R.synthetic_vocab(V, extra=('|',))
+    bias = float(r.choice([0.0, 1.0, 2.5]))
+    tmodel = R.synthetic_init(R.ConditionalLM(H, tv) if conditional else R.RNNLM(H, tv, layers), tv.stoi['|'], bias, 2.0, seed=seed)
+    vocab = T.Vocab.synthetic(V, extra=('|',))
+    lm = T.ConditionalLM(H, vocab) if conditional else T.RNNLM(H, vocab, layers)
+    lm.load_state_dict(tmodel.state_dict())
+    z = r.standard_normal((layers, B, H)).astype(np.float32)
+    kwargs = {'return_z': True}
+    styles = None
+    if conditional:
+        styles = r.randint(0, 2, size=B)
+        kwargs['style'] = torch.from_numpy(styles)
+    d = {'model': lm, 'inputs': torch.from_numpy(z).cuda(), 'vocab': vocab, 'max_len': max_len, 'bos_token': '|', 'eos_token': '|',
+         'substitute_inputs': True, 'inputs_batch_dim': 1, 'kwargs': kwargs}
+    bar = vocab.stoi['|']
+    dec = C.CanonGRUDecoder(tmodel)
+    what = (H, layers, V, B, max_len, mode, conditional)
+    if mode == 'beam':
+        k = int(r.choice([2, 4, 7]))
+        d['beam_size'] = k
+        st = T.InferenceState(d)
+        out = [s.cpu().tolist() for s in st.inference()]
+        want, scores, _, _ = C.beam_decode(dec.session(z, k, style=styles), B, k, max_len, bar, bar, 0.0)
+        assert np.array_equal(st.scores.cpu().numpy(), scores), what
+    elif mode == 'sample':
+        temp, sd = float(r.choice([0.5, 1.0, 1.6])), int(r.randint(1000))
+        d.update(sample_type='sample', temperature=temp, seed=sd)
+        out = [s.cpu().tolist() for s in T.InferenceState(d).inference()]
+        want = C.greedy_decode(dec.session(z, style=styles), B, max_len, bar, bar, sample=(temp, sd))[0]
+    else:
+        out = [s.cpu().tolist() for s in T.InferenceState(d).inference()]
+        want = C.greedy_decode(dec.session(z, style=styles), B, max_len, bar, bar)[0]
+    assert out == want, what
