@@ -1,6 +1,6 @@
 """Seeded random configurations of the decode paths (transformer from cached encoder outputs and from source ids, GRU decoder,
-transformer LM, stateful GRU LMs) (model sizes, head counts, vocabulary, batch, source lengths,
-beam, length penalty, max_len) against the canonical oracle, bit for bit: tokens, hypothesis scores and output lengths.
+transformer LM, stateful GRU LMs; model sizes, head counts, vocabulary, batch, source lengths, beam, length penalty, max_len,
+sampling temperature) against the canonical oracle, bit for bit: tokens, hypothesis scores and output lengths.
 The cases are drawn to reach what the fixed-size tests do not: one-sentence and one-position batches, heads of 8 to 128
 elements, beams wider than the vocabulary's live mass, max_len of 1, sentences that never end, batches that all end at once,
 row counts on both sides of the loop's small-batch switches."""
