@@ -216,3 +216,21 @@ def test_config4_lm_sizes_fp32_sample_and_bf16_properties(T):
     assert len(where) > 5 and all(np.array_equal(g1[0][s], g1b[0][i]) for s, i in where.items())
     agree = float(np.mean([a == b for a, b in zip(rows_as_lists(tok16, lens16, range(2048)), rows_as_lists(tok, lens, range(2048)))]))
     print('\n[config 4] bf16 vs fp32 GPU path: %.0f %% of 2048 beam-8 outputs identical' % (100 * agree))
+
+
+@pytest.mark.parametrize('kind,n_sent,beam,chunk', [('tfm', 45000, 4, 9000), ('gru', 70000, 4, 14000), ('lm_bf16', 14000, 8, 3500)])
+def test_batches_beyond_2_31_elements_equal_chunked_decodes(kind, n_sent, beam, chunk):
+    """Batches whose logits (rows x 32000) and, for the transformers, whose cache of one layer (rows x 50 x width) hold more
+    than 2^31 elements (180 000 / 280 000 / 112 000 rows): every offset in the kernels has to be 64-bit.  A sentence's output
+    does not depend on its batch, so the one large batch must give exactly what the same sentences give in chunks (tokens,
+    lengths, scores).  Runs tools/probe/large_batch.py in a process of its own (it needs 50-115 GB of device memory)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert n_sent * beam * V > 2 ** 31
+    torch.cuda.empty_cache()
+    p = subprocess.run([sys.executable, os.path.join(root, 'tools', 'probe', 'large_batch.py'), str(n_sent), str(beam), str(chunk), kind],
+                       capture_output=True, text=True, timeout=400)
+    assert p.returncode == 0, (p.stdout[-1500:], p.stderr[-1500:])
+    assert 'RESULT identical' in p.stdout
