@@ -8,6 +8,9 @@
  * no allocation, no synchronisation and no global mutable state inside (one thread per stream is
  * safe); sizes are int64_t; the last argument is the hipStream_t to launch on (passed as void*);
  * return value 0 = launched, negative = error (see TST_ERR_*), never an exception.
+ * Row counts, widths, vocabulary sizes and other counts may be at most 2^31 - 1 (TST_ERR_UNSUPPORTED beyond: the
+ * kernels count rows and columns in 32-bit integers); leading dimensions and whole buffers may be larger, every
+ * offset is formed in 64 bits (batches of 280 000 rows x 32000 logits are part of the tests).
  * The _f32 entry points compute in fp32 with a fixed operation order ("canonical arithmetic"): a GEMM output
  * is acc = bias[n]; for k ascending: acc = fma(a[m][k], w[k][n], acc); row reductions use interleaved
  * partial sums combined by an xor-butterfly; exp/log/sigmoid/tanh are fixed polynomials.

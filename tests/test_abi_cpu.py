@@ -133,6 +133,45 @@ def test_gi_table_entry_points_check_their_arguments():
         _lib.call('tst_gru_step_run', gplan, None, None, 2, 7, None)
 
 
+def test_sizes_beyond_31_bits_are_refused_by_every_entry_point():
+    """Row counts, widths and vocabulary sizes above 2^31 - 1 are refused on the host (the kernels count them in 32-bit integers);
+    leading dimensions may be larger.  Random argument lists with one such size in them never reach a launch."""
+    import ctypes
+    import random
+    import re
+    from tst_amd import _lib
+    header = open(os.path.join(ROOT, 'include', 'tst_hip.h')).read()
+    header = re.sub(r'/\*.*?\*/', '', header, flags=re.S)
+    rnd = random.Random(3)
+    checked = 0
+    for name, (args, res) in _lib._PROTOS.items():
+        m = re.search(r'\bint\s+%s\s*\(([^)]*)\)' % name, header)
+        if res is not ctypes.c_int or name.endswith('_ok') or m is None:
+            continue
+        params = [q.strip() for q in m.group(1).split(',')]
+        if len(params) != len(args) or any('tst_' in q for q in params):        # plans are checked through their own tests
+            continue
+        sizes = [i for i, q in enumerate(params) if q.startswith('int64_t')
+                 and not re.match(r'(ld|.*_ld$|.*stride|pad$)', q.split()[-1])]
+        for i in sizes:
+            call = []
+            for j, (t, q) in enumerate(zip(args, params)):
+                if t is _lib.c_vp:
+                    call.append(4096)
+                elif t is _lib.c_f32:
+                    call.append(1.0)
+                else:
+                    call.append(rnd.choice([4, 8, 64, 256]))
+            call[i] = rnd.choice([1 << 31, 1 << 40])
+            call[-1] = None
+            rc = getattr(_lib._dll, name)(*call)
+            assert rc in (-1, -3), (name, params[i], rc)
+            checked += 1
+    assert checked >= 90
+    with pytest.raises(_lib.TstError, match='exceeds 2\\^31 - 1'):
+        _lib.call('tst_layernorm_f32', 16, 16, 16, 1e-5, 16, 4, 1 << 31, None)
+
+
 def test_no_product_module_touches_the_oracle():
     pkg = os.path.join(ROOT, 'text-style-transfer_amd')
     for dirpath, _, files in os.walk(pkg):

@@ -580,6 +580,7 @@ int launch_cross_group(const T* kv, const int32_t* kvrow, const T* q, const uint
 
 extern "C" int tst_attn_self_step_f32(const float* cache, int64_t slab_rows, const int32_t* anc, int64_t anc_ld,
                                       int64_t pos, float* out, int64_t R, int64_t d, int64_t heads, void* stream) {
+    TST_REQUIRE(tst_dims_ok({slab_rows, pos, R, d, heads}), TST_ERR_UNSUPPORTED, "tst_attn_self_step_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(cache && out && (anc || pos == 0), TST_ERR_ARG, "tst_attn_self_step_f32: null pointer");
     TST_REQUIRE(R >= 0 && R <= slab_rows && d > 0 && heads > 0 && d % heads == 0 && (d / heads) % 4 == 0 && pos >= 0,
                 TST_ERR_ARG, "tst_attn_self_step_f32: bad sizes");
@@ -592,6 +593,7 @@ extern "C" int tst_attn_self_step_f32(const float* cache, int64_t slab_rows, con
 
 extern "C" int tst_attn_cross_step_f32(const float* q, const float* kv, const uint8_t* mask, const int32_t* sent,
                                        int64_t S, float* out, int64_t R, int64_t d, int64_t heads, void* stream) {
+    TST_REQUIRE(tst_dims_ok({S, R, d, heads}), TST_ERR_UNSUPPORTED, "tst_attn_cross_step_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(q && kv && sent && out, TST_ERR_ARG, "tst_attn_cross_step_f32: null pointer");
     TST_REQUIRE(R >= 0 && d > 0 && heads > 0 && d % heads == 0 && (d / heads) % 4 == 0 && S > 0, TST_ERR_ARG,
                 "tst_attn_cross_step_f32: bad sizes");
@@ -605,6 +607,7 @@ extern "C" int tst_attn_cross_step_f32(const float* q, const float* kv, const ui
 extern "C" int tst_attn_cross_packed_f32(const float* q, const float* kv, const uint8_t* mask, const int32_t* sent,
                                          const int32_t* kvrow, int64_t S, float* out, int64_t R, int64_t d, int64_t heads,
                                          void* stream) {
+    TST_REQUIRE(tst_dims_ok({S, R, d, heads}), TST_ERR_UNSUPPORTED, "tst_attn_cross_packed_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(q && kv && sent && out && kvrow, TST_ERR_ARG, "tst_attn_cross_packed_f32: null pointer");
     TST_REQUIRE(R >= 0 && d > 0 && heads > 0 && d % heads == 0 && (d / heads) % 4 == 0 && S > 0, TST_ERR_ARG,
                 "tst_attn_cross_packed_f32: bad sizes");
@@ -618,6 +621,7 @@ extern "C" int tst_attn_cross_packed_f32(const float* q, const float* kv, const 
 extern "C" int tst_attn_cross_group_f32(const float* q, const float* kv, const uint8_t* mask, const int32_t* sent,
                                         const int32_t* kvrow, int64_t S, float* out, int64_t R, int64_t d, int64_t heads,
                                         int64_t group, void* stream) {
+    TST_REQUIRE(tst_dims_ok({S, R, d, heads, group}), TST_ERR_UNSUPPORTED, "tst_attn_cross_group_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(q && kv && sent && out, TST_ERR_ARG, "tst_attn_cross_group_f32: null pointer");
     TST_REQUIRE(R >= 0 && d > 0 && heads > 0 && d % heads == 0 && (d / heads) % 4 == 0 && S > 0 && group >= 1, TST_ERR_ARG,
                 "tst_attn_cross_group_f32: bad sizes");
@@ -640,6 +644,7 @@ extern "C" int tst_attn_cross_group_f32(const float* q, const float* kv, const u
 // bf16 storage (cache, q, k|v and output), fp32 arithmetic in the same order as the fp32 kernels
 extern "C" int tst_attn_self_step_bf16(const void* cache, int64_t slab_rows, const int32_t* anc, int64_t anc_ld,
                                        int64_t pos, void* out, int64_t R, int64_t d, int64_t heads, void* stream) {
+    TST_REQUIRE(tst_dims_ok({slab_rows, pos, R, d, heads}), TST_ERR_UNSUPPORTED, "tst_attn_self_step_bf16: a size exceeds 2^31 - 1");
     TST_REQUIRE(cache && out && (anc || pos == 0), TST_ERR_ARG, "tst_attn_self_step_bf16: null pointer");
     TST_REQUIRE(R >= 0 && R <= slab_rows && d > 0 && heads > 0 && d % heads == 0 && (d / heads) % 4 == 0 && pos >= 0,
                 TST_ERR_ARG, "tst_attn_self_step_bf16: bad sizes");
@@ -652,6 +657,7 @@ extern "C" int tst_attn_self_step_bf16(const void* cache, int64_t slab_rows, con
 
 extern "C" int tst_attn_cross_step_bf16(const void* q, const void* kv, const uint8_t* mask, const int32_t* sent, int64_t S,
                                         void* out, int64_t R, int64_t d, int64_t heads, void* stream) {
+    TST_REQUIRE(tst_dims_ok({S, R, d, heads}), TST_ERR_UNSUPPORTED, "tst_attn_cross_step_bf16: a size exceeds 2^31 - 1");
     TST_REQUIRE(q && kv && sent && out, TST_ERR_ARG, "tst_attn_cross_step_bf16: null pointer");
     TST_REQUIRE(R >= 0 && d > 0 && heads > 0 && d % heads == 0 && (d / heads) % 4 == 0 && S > 0, TST_ERR_ARG,
                 "tst_attn_cross_step_bf16: bad sizes");
@@ -668,6 +674,7 @@ extern "C" int tst_attn_cross_step_bf16(const void* q, const void* kv, const uin
 // used by tst_tfm_step_run.
 extern "C" int tst_attn_cross_mfma_f32(const float* q, const float* kv, const uint8_t* mask, const int32_t* sent, const int32_t* kvrow,
                                        int64_t S, float* out, int64_t R, int64_t d, int64_t heads, int64_t group, void* stream) {
+    TST_REQUIRE(tst_dims_ok({S, R, d, heads, group}), TST_ERR_UNSUPPORTED, "tst_attn_cross_mfma_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(q && kv && sent && out, TST_ERR_ARG, "tst_attn_cross_mfma_f32: null pointer");
     TST_REQUIRE(R >= 0 && d > 0 && heads > 0 && d % heads == 0 && S > 0 && group >= 1, TST_ERR_ARG, "tst_attn_cross_mfma_f32: bad sizes");
     TST_REQUIRE(kvrow == nullptr || mask != nullptr, TST_ERR_ARG, "tst_attn_cross_mfma_f32: a packed k|v needs the mask");

@@ -390,6 +390,7 @@ extern "C" int tst_chain_ok(int64_t R, int64_t d, int64_t K1, int64_t N2) {
 extern "C" int tst_chain_f32(const float* A, int64_t lda, int64_t K1, const float* W1t, int64_t ldw1, const float* b1, float* x,
                              const float* gamma, const float* beta, float eps, const float* W2t, int64_t ldw2, const float* b2, int act2,
                              float* C, int64_t ldc, int64_t N2, float* yT, int64_t ldt, int64_t R, int64_t d, void* stream) {
+    TST_REQUIRE(tst_dims_ok({K1, N2, R, d}), TST_ERR_UNSUPPORTED, "tst_chain_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(A && W1t && x && gamma && beta, TST_ERR_ARG, "tst_chain_f32: null pointer");
     TST_REQUIRE(R >= 0 && (act2 == 0 || act2 == 1), TST_ERR_ARG, "tst_chain_f32: bad sizes");
     if (R == 0) return TST_OK;

@@ -816,6 +816,7 @@ int tst_bf16_forced_shape() {
 extern "C" int tst_gemm_mfma_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias,
                                   const float* res, int64_t ldr, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                                   int act, int out_bf16, void* stream) {
+    TST_REQUIRE(tst_dims_ok({M, N, K}), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_bf16: a size exceeds 2^31 - 1");
     TST_REQUIRE(A && W && C, TST_ERR_ARG, "tst_gemm_mfma_bf16: null pointer");
     TST_REQUIRE(M >= 0 && N > 0 && K >= 8 && (act == 0 || act == 1), TST_ERR_ARG, "tst_gemm_mfma_bf16: bad sizes M=%lld N=%lld K=%lld",
                 (long long)M, (long long)N, (long long)K);
@@ -912,6 +913,7 @@ extern "C" int tst_gemm_res_ln_ok(int64_t M, int64_t N, int64_t K) {
 
 extern "C" int tst_gemm_res_ln_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, float* x, const float* gamma,
                                     const float* beta, float eps, void* h, int64_t ldh, int64_t M, int64_t N, int64_t K, void* stream) {
+    TST_REQUIRE(tst_dims_ok({M, N, K}), TST_ERR_UNSUPPORTED, "tst_gemm_res_ln_bf16: a size exceeds 2^31 - 1");
     TST_REQUIRE(A && W && x && gamma && beta && h, TST_ERR_ARG, "tst_gemm_res_ln_bf16: null pointer");
     TST_REQUIRE(M >= 0, TST_ERR_ARG, "tst_gemm_res_ln_bf16: bad sizes");
     if (M == 0) return TST_OK;
@@ -939,6 +941,7 @@ extern "C" int tst_vocab_stats_ok(int64_t M, int64_t N, int64_t K) {
 
 extern "C" int tst_vocabproj_stats_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, const float* bias, void* C, int64_t ldc,
                                         int64_t M, int64_t N, int64_t K, float* part, int64_t n_slices, void* stream) {
+    TST_REQUIRE(tst_dims_ok({M, N, K, n_slices}), TST_ERR_UNSUPPORTED, "tst_vocabproj_stats_bf16: a size exceeds 2^31 - 1");
     TST_REQUIRE(A && W && C && part, TST_ERR_ARG, "tst_vocabproj_stats_bf16: null pointer");
     TST_REQUIRE(tst_vocab_stats_ok(M, N, K), TST_ERR_UNSUPPORTED,
                 "tst_vocabproj_stats_bf16: M=%lld N=%lld K=%lld is not a shape of the persistent kernel (tst_vocab_stats_ok)", (long long)M,

@@ -932,6 +932,7 @@ int check_gemm_args(const char* who, const float* A, int64_t lda, const float* W
 extern "C" int tst_gemm_skinny_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias,
                                    const float* res, int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                                    int act, int strip, void* stream) {
+    TST_REQUIRE(tst_dims_ok({M, N, K}), TST_ERR_UNSUPPORTED, "tst_gemm_skinny_f32: a size exceeds 2^31 - 1");
     const int rc = check_gemm_args("tst_gemm_skinny_f32", A, lda, Wt, ldw, res, ldr, C, ldc, M, N, K, act);
     if (rc != TST_OK) return rc;
     TST_REQUIRE(strip == 1 || strip == 2 || strip == 4, TST_ERR_ARG, "tst_gemm_skinny_f32: strip must be 1, 2 or 4");
@@ -946,6 +947,7 @@ extern "C" int tst_gemm_skinny_f32(const float* A, int64_t lda, const float* Wt,
 extern "C" int tst_ln_gemm_f32(const float* x, const float* gamma, const float* beta, float eps, float* h, const float* Wt,
                                int64_t ldw, const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K, int act,
                                void* stream) {
+    TST_REQUIRE(tst_dims_ok({M, N, K}), TST_ERR_UNSUPPORTED, "tst_ln_gemm_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(x && gamma && beta && h, TST_ERR_ARG, "tst_ln_gemm_f32: null pointer");
     const int rc = check_gemm_args("tst_ln_gemm_f32", x, K, Wt, ldw, nullptr, 0, C, ldc, M, N, K, act);
     if (rc != TST_OK) return rc;
@@ -971,6 +973,7 @@ extern "C" int tst_vocab_argmax_ok(int64_t R, int64_t V, int64_t d) {
 
 extern "C" int tst_ln_vocab_argmax_f32(const float* x, const float* gamma, const float* beta, float eps, const float* Wt, int64_t ldw,
                                        const float* bias, uint64_t* keys, int64_t R, int64_t V, int64_t d, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, V, d}), TST_ERR_UNSUPPORTED, "tst_ln_vocab_argmax_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(x && gamma && beta && Wt && keys, TST_ERR_ARG, "tst_ln_vocab_argmax_f32: null pointer");   // keys: [R][TST_ARGMAX_SLOTS]
     TST_REQUIRE(R >= 0 && V > 0 && ldw % 4 == 0 && ldw >= V && ldw >= 4, TST_ERR_ARG, "tst_ln_vocab_argmax_f32: bad sizes (ldw %% 4 == 0, ldw >= V)");
     TST_REQUIRE(tst_aligned16(x) && tst_aligned16(gamma) && tst_aligned16(beta) && tst_aligned16(Wt) && tst_aligned16(keys),
@@ -992,6 +995,7 @@ extern "C" int tst_ln_vocab_argmax_f32(const float* x, const float* gamma, const
 extern "C" int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias,
                                  const float* res, int64_t ldr, float* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
                                  int act, void* stream) {
+    TST_REQUIRE(tst_dims_ok({M, N, K}), TST_ERR_UNSUPPORTED, "tst_gemm_mfma_f32: a size exceeds 2^31 - 1");
     const int rc = check_gemm_args("tst_gemm_mfma_f32", A, lda, Wt, ldw, res, ldr, C, ldc, M, N, K, act);
     if (rc != TST_OK) return rc;
     if (M == 0) return TST_OK;

@@ -439,6 +439,7 @@ __global__ __launch_bounds__(256) void layernorm_t_kernel(const float* __restric
 
 extern "C" int tst_layernorm_t_f32(const float* x, const float* gamma, const float* beta, float eps, float* yT, int64_t ldt, int64_t R,
                                    int64_t d, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, d}), TST_ERR_UNSUPPORTED, "tst_layernorm_t_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(x && gamma && beta && yT, TST_ERR_ARG, "tst_layernorm_t_f32: null pointer");
     TST_REQUIRE(R >= 0 && d >= 4 && d % 4 == 0 && ldt >= R, TST_ERR_ARG, "tst_layernorm_t_f32: bad sizes (d %% 4 == 0, ldt >= R)");
     TST_REQUIRE(d <= 512, TST_ERR_UNSUPPORTED, "tst_layernorm_t_f32: rows of at most 512 elements (a 64-row block is staged in LDS)");
@@ -472,6 +473,7 @@ void launch_plain128(const float* AT, int64_t ldat, const float* Wt, int64_t ldw
 
 extern "C" int tst_gemm_dma_f32(const float* AT, int64_t ldat, const float* Wt, int64_t ldw, const float* bias, float* C, int64_t ldc,
                                 int64_t M, int64_t N, int64_t K, int variant, void* stream) {
+    TST_REQUIRE(tst_dims_ok({M, N, K}), TST_ERR_UNSUPPORTED, "tst_gemm_dma_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(AT && Wt && C, TST_ERR_ARG, "tst_gemm_dma_f32: null pointer");
     TST_REQUIRE(M >= 0 && N > 0 && K >= 16 && K % 16 == 0, TST_ERR_ARG, "tst_gemm_dma_f32: bad sizes (K must be a multiple of 16)");
     const int64_t tiles_m = (M + 127) / 128, tiles_n = (N + TN - 1) / TN;

@@ -268,6 +268,7 @@ int gru_cell_fused_impl(const char* who, const float* x, int64_t ldx, const floa
 extern "C" int tst_gru_cell_fused_tab_f32(const float* gi_tab, int64_t ld_tab, const int32_t* tok, int64_t V, const float* h, int64_t ldh,
                                           const float* whh, int64_t ld_whh, const float* bhh, float* h_out, int64_t ldo, float* h_out_t,
                                           int64_t ldt, int64_t R, int64_t H, void* stream) {
+    TST_REQUIRE(tst_dims_ok({V, R, H}), TST_ERR_UNSUPPORTED, "tst_gru_cell_fused_tab_f32: a size exceeds 2^31 - 1");
     const char* who = "tst_gru_cell_fused_tab_f32";
     TST_REQUIRE(gi_tab && tok && h && whh && h_out, TST_ERR_ARG, "%s: null pointer", who);
     TST_REQUIRE(R >= 0 && R < (1ll << 31) && H > 0 && V > 0 && V < (1ll << 31), TST_ERR_ARG, "%s: bad sizes", who);
@@ -298,6 +299,7 @@ extern "C" int tst_gru_cell_fused_tab_f32(const float* gi_tab, int64_t ld_tab, c
 extern "C" int tst_gru_cell_fused_f32(const float* x, int64_t ldx, const float* h, int64_t ldh, const float* wih, int64_t ld_wih,
                                       const float* bih, const float* whh, int64_t ld_whh, const float* bhh, float* h_out,
                                       int64_t ldo, int64_t R, int64_t E, int64_t H, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, E, H}), TST_ERR_UNSUPPORTED, "tst_gru_cell_fused_f32: a size exceeds 2^31 - 1");
     return gru_cell_fused_impl("tst_gru_cell_fused_f32", x, ldx, h, ldh, wih, ld_wih, bih, whh, ld_whh, bhh, h_out, ldo, nullptr, 0, R, E, H,
                                stream);
 }
@@ -305,6 +307,7 @@ extern "C" int tst_gru_cell_fused_f32(const float* x, int64_t ldx, const float* 
 extern "C" int tst_gru_cell_fused_t_f32(const float* x, int64_t ldx, const float* h, int64_t ldh, const float* wih, int64_t ld_wih,
                                         const float* bih, const float* whh, int64_t ld_whh, const float* bhh, float* h_out,
                                         int64_t ldo, float* h_out_t, int64_t ldt, int64_t R, int64_t E, int64_t H, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, E, H}), TST_ERR_UNSUPPORTED, "tst_gru_cell_fused_t_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(h_out_t != nullptr, TST_ERR_ARG, "tst_gru_cell_fused_t_f32: null h_out_t");
     return gru_cell_fused_impl("tst_gru_cell_fused_t_f32", x, ldx, h, ldh, wih, ld_wih, bih, whh, ld_whh, bhh, h_out, ldo, h_out_t, ldt, R,
                                E, H, stream);

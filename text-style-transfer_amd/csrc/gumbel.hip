@@ -94,6 +94,7 @@ __global__ __launch_bounds__(256) void mix_logprobs_kernel(const float* __restri
 
 extern "C" int tst_mix_logprobs_f32(const float* logits, int64_t model_stride, int64_t ld, int64_t n_models,
                                     const float* weights, int64_t R, int64_t V, float* out, int64_t ldo, void* stream) {
+    TST_REQUIRE(tst_dims_ok({n_models, R, V}), TST_ERR_UNSUPPORTED, "tst_mix_logprobs_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(logits && weights && out, TST_ERR_ARG, "tst_mix_logprobs_f32: null pointer");
     TST_REQUIRE(R >= 0 && V > 0 && ld >= V && ldo >= V && V < (1ll << 30) && R < (1ll << 31) && model_stride >= 0, TST_ERR_ARG,
                 "tst_mix_logprobs_f32: bad sizes");
@@ -106,6 +107,7 @@ extern "C" int tst_mix_logprobs_f32(const float* logits, int64_t model_stride, i
 
 extern "C" int tst_gumbel_softmax_f32(const float* logits, int64_t ld, int64_t R, int64_t V, const float* u, int64_t ldu,
                                       float temperature, float* out, int64_t ldo, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, V}), TST_ERR_UNSUPPORTED, "tst_gumbel_softmax_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(logits && u && out, TST_ERR_ARG, "tst_gumbel_softmax_f32: null pointer");
     TST_REQUIRE(R >= 0 && V > 0 && ld >= V && ldu >= V && ldo >= V && V < (1ll << 30) && R < (1ll << 31), TST_ERR_ARG,
                 "tst_gumbel_softmax_f32: bad sizes");

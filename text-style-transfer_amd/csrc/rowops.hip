@@ -279,6 +279,7 @@ __global__ __launch_bounds__(256) void pack_write_kernel(const int64_t* __restri
 
 extern "C" int tst_embed_posadd_f32(const int32_t* tok, const float* emb, const float* pe, const int32_t* pos, float scale,
                                     float* x, int64_t R, int64_t d, int64_t V, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, d, V}), TST_ERR_UNSUPPORTED, "tst_embed_posadd_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(tok && emb && x && (pe || !pos), TST_ERR_ARG, "tst_embed_posadd_f32: null pointer");
     TST_REQUIRE(R >= 0 && d > 0 && d % 4 == 0 && V > 0, TST_ERR_ARG, "tst_embed_posadd_f32: need d %% 4 == 0, V > 0");
     TST_REQUIRE(tst_aligned16(emb) && tst_aligned16(x) && tst_aligned16(pe), TST_ERR_ARG, "tst_embed_posadd_f32: alignment");
@@ -291,6 +292,7 @@ extern "C" int tst_embed_posadd_f32(const int32_t* tok, const float* emb, const 
 
 extern "C" int tst_embed_posadd_rows_f32(const int32_t* tok, const float* emb, const float* pe, const int32_t* pos, float scale,
                                          const float* z, const int32_t* zidx, float* x, int64_t R, int64_t d, int64_t V, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, d, V}), TST_ERR_UNSUPPORTED, "tst_embed_posadd_rows_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(tok && emb && x && (pe || !pos) && z && zidx, TST_ERR_ARG, "tst_embed_posadd_rows_f32: null pointer");
     TST_REQUIRE(R >= 0 && d > 0 && d % 4 == 0 && V > 0, TST_ERR_ARG, "tst_embed_posadd_rows_f32: need d %% 4 == 0, V > 0");
     TST_REQUIRE(tst_aligned16(emb) && tst_aligned16(x) && tst_aligned16(pe) && tst_aligned16(z), TST_ERR_ARG, "tst_embed_posadd_rows_f32: alignment");
@@ -316,6 +318,7 @@ int tst_embed_posadd_clear_f32(const int32_t* tok, const float* emb, const float
 }
 
 extern "C" int tst_scale_posadd_f32(float* x, float scale, const float* pe, int64_t R, int64_t d, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, d}), TST_ERR_UNSUPPORTED, "tst_scale_posadd_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(x, TST_ERR_ARG, "tst_scale_posadd_f32: null pointer");
     TST_REQUIRE(R >= 0 && d > 0 && d % 4 == 0, TST_ERR_ARG, "tst_scale_posadd_f32: need d %% 4 == 0");
     TST_REQUIRE(tst_aligned16(x) && tst_aligned16(pe), TST_ERR_ARG, "tst_scale_posadd_f32: alignment");
@@ -328,6 +331,7 @@ extern "C" int tst_scale_posadd_f32(float* x, float scale, const float* pe, int6
 
 extern "C" int tst_layernorm_f32(const float* x, const float* gamma, const float* beta, float eps, float* y, int64_t R,
                                  int64_t d, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, d}), TST_ERR_UNSUPPORTED, "tst_layernorm_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(x && gamma && beta && y, TST_ERR_ARG, "tst_layernorm_f32: null pointer");
     TST_REQUIRE(R >= 0 && d > 0 && d % 4 == 0, TST_ERR_ARG, "tst_layernorm_f32: need d %% 4 == 0");
     TST_REQUIRE(tst_aligned16(x) && tst_aligned16(y) && tst_aligned16(gamma) && tst_aligned16(beta), TST_ERR_ARG,
@@ -339,6 +343,7 @@ extern "C" int tst_layernorm_f32(const float* x, const float* gamma, const float
 
 extern "C" int tst_layernorm_f32_bf16(const float* x, const float* gamma, const float* beta, float eps, void* y, int64_t R,
                                       int64_t d, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, d}), TST_ERR_UNSUPPORTED, "tst_layernorm_f32_bf16: a size exceeds 2^31 - 1");
     TST_REQUIRE(x && gamma && beta && y, TST_ERR_ARG, "tst_layernorm_f32_bf16: null pointer");
     TST_REQUIRE(R >= 0 && d > 0 && d % 4 == 0, TST_ERR_ARG, "tst_layernorm_f32_bf16: need d %% 4 == 0");
     TST_REQUIRE(tst_aligned16(x) && tst_aligned16(y) && tst_aligned16(gamma) && tst_aligned16(beta), TST_ERR_ARG,
@@ -349,6 +354,7 @@ extern "C" int tst_layernorm_f32_bf16(const float* x, const float* gamma, const 
 }
 
 extern "C" int tst_add_rows_f32(float* x, const float* z, const int32_t* idx, int64_t R, int64_t d, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, d}), TST_ERR_UNSUPPORTED, "tst_add_rows_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(x && z && idx, TST_ERR_ARG, "tst_add_rows_f32: null pointer");
     TST_REQUIRE(R >= 0 && d > 0 && d % 4 == 0, TST_ERR_ARG, "tst_add_rows_f32: need d %% 4 == 0");
     TST_REQUIRE(tst_aligned16(x) && tst_aligned16(z), TST_ERR_ARG, "tst_add_rows_f32: alignment");
@@ -360,6 +366,7 @@ extern "C" int tst_add_rows_f32(float* x, const float* z, const int32_t* idx, in
 
 extern "C" int tst_gru_cell_step_tab_f32(const float* gi_tab, int64_t ld_tab, const int32_t* tok, int64_t V, const float* gh, const float* h,
                                          float* h_out, int64_t R, int64_t H, void* stream) {
+    TST_REQUIRE(tst_dims_ok({V, R, H}), TST_ERR_UNSUPPORTED, "tst_gru_cell_step_tab_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(gi_tab && tok && gh && h && h_out, TST_ERR_ARG, "tst_gru_cell_step_tab_f32: null pointer");
     TST_REQUIRE(R >= 0 && H > 0 && H % 4 == 0 && V > 0 && V < (1ll << 31) && ld_tab >= 3 * H && ld_tab % 4 == 0, TST_ERR_ARG,
                 "tst_gru_cell_step_tab_f32: need H %% 4 == 0, V > 0, ld_tab %% 4 == 0, ld_tab >= 3 H");
@@ -373,6 +380,7 @@ extern "C" int tst_gru_cell_step_tab_f32(const float* gi_tab, int64_t ld_tab, co
 
 extern "C" int tst_gru_cell_step_f32(const float* gi, const float* gh, const float* h, float* h_out, int64_t R, int64_t H,
                                      void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, H}), TST_ERR_UNSUPPORTED, "tst_gru_cell_step_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(gi && gh && h && h_out, TST_ERR_ARG, "tst_gru_cell_step_f32: null pointer");
     TST_REQUIRE(R >= 0 && H > 0 && H % 4 == 0, TST_ERR_ARG, "tst_gru_cell_step_f32: need H %% 4 == 0");
     TST_REQUIRE(tst_aligned16(gi) && tst_aligned16(gh) && tst_aligned16(h) && tst_aligned16(h_out), TST_ERR_ARG,
@@ -385,6 +393,7 @@ extern "C" int tst_gru_cell_step_f32(const float* gi, const float* gh, const flo
 
 extern "C" int tst_gather_rows_f32(const float* src, const int32_t* idx, float* dst, int64_t R, int64_t width,
                                    void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, width}), TST_ERR_UNSUPPORTED, "tst_gather_rows_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(src && idx && dst && src != dst, TST_ERR_ARG, "tst_gather_rows_f32: null or aliased pointer");
     TST_REQUIRE(R >= 0 && width > 0 && width % 4 == 0, TST_ERR_ARG, "tst_gather_rows_f32: need width %% 4 == 0");
     TST_REQUIRE(tst_aligned16(src) && tst_aligned16(dst), TST_ERR_ARG, "tst_gather_rows_f32: alignment");
@@ -395,6 +404,7 @@ extern "C" int tst_gather_rows_f32(const float* src, const int32_t* idx, float* 
 }
 
 extern "C" int tst_scatter_rows_f32(const float* src, const int32_t* idx, float* dst, int64_t R, int64_t width, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, width}), TST_ERR_UNSUPPORTED, "tst_scatter_rows_f32: a size exceeds 2^31 - 1");
     TST_REQUIRE(src && idx && dst && src != dst, TST_ERR_ARG, "tst_scatter_rows_f32: null or aliased pointer");
     TST_REQUIRE(R >= 0 && width > 0 && width % 4 == 0, TST_ERR_ARG, "tst_scatter_rows_f32: need width %% 4 == 0");
     TST_REQUIRE(tst_aligned16(src) && tst_aligned16(dst), TST_ERR_ARG, "tst_scatter_rows_f32: alignment");
@@ -406,6 +416,7 @@ extern "C" int tst_scatter_rows_f32(const float* src, const int32_t* idx, float*
 
 extern "C" int tst_pack_sources(const int64_t* src, int64_t pad, int64_t B, int64_t S, uint8_t* mask, int32_t* kvrow, int32_t* tok,
                                 int32_t* pos, int32_t* sent, int32_t* padded_row, int32_t* work, int32_t* n_live, void* stream) {
+    TST_REQUIRE(tst_dims_ok({B, S}), TST_ERR_UNSUPPORTED, "tst_pack_sources: a size exceeds 2^31 - 1");
     TST_REQUIRE(src && mask && kvrow && tok && pos && sent && padded_row && work && n_live, TST_ERR_ARG, "tst_pack_sources: null pointer");
     TST_REQUIRE(B >= 0 && S > 0 && B * S < (1ll << 31), TST_ERR_ARG, "tst_pack_sources: bad sizes");
     hipStream_t st = (hipStream_t)stream;

@@ -811,36 +811,43 @@ bool rows_ok(const tst_rows* r, bool need_anc) {
 }  // namespace
 
 extern "C" int tst_argmax_rows_f32(const float* logits, int64_t ld, int64_t R, int64_t V, int32_t* tok, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, V}), TST_ERR_UNSUPPORTED, "tst_argmax_rows_f32: a size exceeds 2^31 - 1");
     return argmax_entry<float>(logits, ld, R, V, tok, stream, "tst_argmax_rows_f32");
 }
 
 extern "C" int tst_argmax_rows_bf16(const void* logits, int64_t ld, int64_t R, int64_t V, int32_t* tok, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, V}), TST_ERR_UNSUPPORTED, "tst_argmax_rows_bf16: a size exceeds 2^31 - 1");
     return argmax_entry<__bf16>((const __bf16*)logits, ld, R, V, tok, stream, "tst_argmax_rows_bf16");
 }
 
 extern "C" int tst_sample_rows_f32(const float* logits, int64_t ld, int64_t R, int64_t V, float temperature, uint32_t seed,
                                    uint32_t step, const int32_t* sent, int32_t* tok, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, V}), TST_ERR_UNSUPPORTED, "tst_sample_rows_f32: a size exceeds 2^31 - 1");
     return sample_entry<float>(logits, ld, R, V, temperature, seed, step, sent, tok, stream, "tst_sample_rows_f32");
 }
 
 extern "C" int tst_sample_rows_bf16(const void* logits, int64_t ld, int64_t R, int64_t V, float temperature, uint32_t seed,
                                     uint32_t step, const int32_t* sent, int32_t* tok, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, V}), TST_ERR_UNSUPPORTED, "tst_sample_rows_bf16: a size exceeds 2^31 - 1");
     return sample_entry<__bf16>((const __bf16*)logits, ld, R, V, temperature, seed, step, sent, tok, stream,
                                 "tst_sample_rows_bf16");
 }
 
 extern "C" int tst_logsoftmax_topk_f32(const float* logits, int64_t ld, int64_t R, int64_t V, int64_t k, float* top_val,
                                        int32_t* top_idx, float* lse, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, V, k}), TST_ERR_UNSUPPORTED, "tst_logsoftmax_topk_f32: a size exceeds 2^31 - 1");
     return topk_entry<float>(logits, ld, R, V, k, top_val, top_idx, lse, stream, "tst_logsoftmax_topk_f32");
 }
 
 extern "C" int tst_logsoftmax_topk_bf16(const void* logits, int64_t ld, int64_t R, int64_t V, int64_t k, float* top_val,
                                         int32_t* top_idx, float* lse, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, V, k}), TST_ERR_UNSUPPORTED, "tst_logsoftmax_topk_bf16: a size exceeds 2^31 - 1");
     return topk_entry<__bf16>((const __bf16*)logits, ld, R, V, k, top_val, top_idx, lse, stream, "tst_logsoftmax_topk_bf16");
 }
 
 extern "C" int tst_topk_from_stats_bf16(const void* logits, int64_t ld, const float* part, int64_t n_slices, int64_t R, int64_t V,
                                         int64_t k, float* top_val, int32_t* top_idx, float* lse, void* stream) {
+    TST_REQUIRE(tst_dims_ok({n_slices, R, V, k}), TST_ERR_UNSUPPORTED, "tst_topk_from_stats_bf16: a size exceeds 2^31 - 1");
     TST_REQUIRE(logits && part && top_val && top_idx && lse, TST_ERR_ARG, "tst_topk_from_stats_bf16: null pointer");
     TST_REQUIRE(R >= 0 && R < (1ll << 31) && V > 0 && ld >= V && k >= 1 && k <= 8 && k <= V, TST_ERR_ARG, "tst_topk_from_stats_bf16: bad sizes");
     TST_REQUIRE(V % 8 == 0 && ld % 8 == 0 && tst_aligned16(logits) && tst_aligned16(part), TST_ERR_ARG,
@@ -870,6 +877,7 @@ extern "C" int tst_topk_from_stats_bf16(const void* logits, int64_t ld, const fl
 extern "C" int tst_greedy_select(const int32_t* argmax_tok, int64_t n_rows, int32_t eos, int32_t* sel_parent,
                                  int32_t* sel_tok, float* sel_score, int32_t* sel_fin, int32_t* sel_nemit,
                                  const tst_rows* cur, void* stream) {
+    TST_REQUIRE(tst_dims_ok({n_rows}), TST_ERR_UNSUPPORTED, "tst_greedy_select: a size exceeds 2^31 - 1");
     TST_REQUIRE(argmax_tok && sel_parent && sel_tok && sel_score && sel_fin && sel_nemit && rows_ok(cur, false), TST_ERR_ARG,
                 "tst_greedy_select: null pointer");
     TST_REQUIRE(n_rows >= 0, TST_ERR_ARG, "tst_greedy_select: bad size");
@@ -882,6 +890,7 @@ extern "C" int tst_greedy_select(const int32_t* argmax_tok, int64_t n_rows, int3
 extern "C" int tst_beam_merge(const tst_rows* cur, const float* top_val, const int32_t* top_idx, const float* lse,
                               int64_t n_sent, int64_t k, int64_t k_in, int32_t eos, int32_t* sel_parent, int32_t* sel_tok,
                               float* sel_score, int32_t* sel_fin, int32_t* sel_nemit, void* stream) {
+    TST_REQUIRE(tst_dims_ok({n_sent, k, k_in}), TST_ERR_UNSUPPORTED, "tst_beam_merge: a size exceeds 2^31 - 1");
     TST_REQUIRE(rows_ok(cur, false) && top_val && top_idx && lse && sel_parent && sel_tok && sel_score && sel_fin &&
                     sel_nemit, TST_ERR_ARG, "tst_beam_merge: null pointer");
     TST_REQUIRE(n_sent >= 0 && k >= 1 && k <= 8 && k_in >= 1 && k_in <= k, TST_ERR_ARG,
@@ -937,6 +946,7 @@ extern "C" int tst_retire_compact(const tst_rows* cur, const tst_rows* nxt, cons
                                   int64_t T, int32_t eos, int last_step, int top_ends, int32_t* out_tok,
                                   int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent,
                                   int32_t* n_alive, void* stream) {
+    TST_REQUIRE(tst_dims_ok({n_sent, k, step, T}), TST_ERR_UNSUPPORTED, "tst_retire_compact: a size exceeds 2^31 - 1");
     return retire_compact_impl(cur, nxt, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, lp, n_sent, k, step, T, eos, last_step,
                                top_ends, out_tok, out_len, out_score, scratch_alive_pos, row_parent, n_alive, stream,
                                "tst_retire_compact");
@@ -978,6 +988,7 @@ extern "C" int tst_retire_compact_noalloc(const tst_rows* cur, const tst_rows* n
                                           int64_t T, int32_t eos, int last_step, int top_ends, int32_t* out_tok,
                                           int32_t* out_len, float* out_score, int32_t* row_parent, int32_t* n_alive,
                                           void* stream) {
+    TST_REQUIRE(tst_dims_ok({n_sent, k, step, T}), TST_ERR_UNSUPPORTED, "tst_retire_compact_noalloc: a size exceeds 2^31 - 1");
     TST_REQUIRE(n_sent <= TST_NOALLOC_MAX_SENT, TST_ERR_UNSUPPORTED,
                 "tst_retire_compact_noalloc: %lld sentences, the built-in scratch holds %d (use tst_retire_compact with a buffer)",
                 (long long)n_sent, TST_NOALLOC_MAX_SENT);
@@ -1029,6 +1040,7 @@ extern "C" int tst_greedy_retire_compact(const int32_t* argmax_tok, const tst_ro
                                          int64_t n_sent, int64_t step, int64_t T, int32_t eos, int last_step, int32_t* out_tok,
                                          int32_t* out_len, float* out_score, int32_t* scratch_alive_pos, int32_t* row_parent,
                                          int32_t* n_alive, void* stream) {
+    TST_REQUIRE(tst_dims_ok({n_sent, step, T}), TST_ERR_UNSUPPORTED, "tst_greedy_retire_compact: a size exceeds 2^31 - 1");
     return greedy_retire_compact_impl(argmax_tok, cur, nxt, sel_parent, sel_tok, sel_score, sel_fin, sel_nemit, lp, n_sent, step, T, eos,
                                       last_step, out_tok, out_len, out_score, scratch_alive_pos, row_parent, n_alive, stream, nullptr);
 }

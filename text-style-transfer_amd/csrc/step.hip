@@ -66,6 +66,7 @@ bool tst_tfm_chain() {
 
 extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const int32_t* anc, const int32_t* sent, int64_t R,
                                 int64_t t, int phases, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R, t}), TST_ERR_UNSUPPORTED, "tst_tfm_step_run: a size exceeds 2^31 - 1");
     TST_REQUIRE(m != nullptr && m->layers != nullptr, TST_ERR_ARG, "tst_tfm_step_run: null plan");
     TST_REQUIRE(m->n_layers >= 1 && m->d > 0 && m->heads > 0 && m->d_ff > 0 && m->V > 0, TST_ERR_ARG, "tst_tfm_step_run: bad sizes");
     TST_REQUIRE(R >= 0 && R <= m->slab_rows, TST_ERR_ARG, "tst_tfm_step_run: %lld rows, buffers hold %lld", (long long)R,
@@ -208,6 +209,7 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
 }
 
 extern "C" int tst_gru_step_run(const tst_gru_step* m, const int32_t* tok, const int32_t* sent, int64_t R, int phases, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R}), TST_ERR_UNSUPPORTED, "tst_gru_step_run: a size exceeds 2^31 - 1");
     TST_REQUIRE(m != nullptr && m->layers != nullptr, TST_ERR_ARG, "tst_gru_step_run: null plan");
     TST_REQUIRE(m->n_layers >= 1 && m->E > 0 && m->H > 0 && m->V > 0, TST_ERR_ARG, "tst_gru_step_run: bad sizes");
     TST_REQUIRE(R >= 0 && R <= m->rows, TST_ERR_ARG, "tst_gru_step_run: %lld rows, buffers hold %lld", (long long)R, (long long)m->rows);
@@ -282,6 +284,7 @@ extern "C" int tst_gru_step_run(const tst_gru_step* m, const int32_t* tok, const
 }
 
 extern "C" int tst_gru_reorder_run(const tst_gru_step* m, const int32_t* row_parent, int64_t R, void* stream) {
+    TST_REQUIRE(tst_dims_ok({R}), TST_ERR_UNSUPPORTED, "tst_gru_reorder_run: a size exceeds 2^31 - 1");
     TST_REQUIRE(m != nullptr && m->layers != nullptr && row_parent != nullptr, TST_ERR_ARG, "tst_gru_reorder_run: null pointer");
     TST_REQUIRE(R >= 0 && R <= m->rows, TST_ERR_ARG, "tst_gru_reorder_run: %lld rows, buffers hold %lld", (long long)R,
                 (long long)m->rows);
@@ -294,6 +297,7 @@ extern "C" int tst_gru_reorder_run(const tst_gru_step* m, const int32_t* row_par
 
 extern "C" int tst_select_step_run(const tst_select_step* s, const tst_rows* cur, const tst_rows* nxt, int64_t n_sent, int64_t k_in,
                                    int64_t step, uint32_t sample_step, int last_step, void* stream) {
+    TST_REQUIRE(tst_dims_ok({n_sent, k_in, step}), TST_ERR_UNSUPPORTED, "tst_select_step_run: a size exceeds 2^31 - 1");
     TST_REQUIRE(s != nullptr && cur != nullptr && nxt != nullptr, TST_ERR_ARG, "tst_select_step_run: null pointer");
     TST_REQUIRE(s->k >= 1 && s->k <= 8 && (k_in == 1 || k_in == s->k) && n_sent >= 0, TST_ERR_ARG, "tst_select_step_run: bad sizes");
     const int64_t R = n_sent * k_in;

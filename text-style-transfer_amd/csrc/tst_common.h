@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <initializer_list>
 #include "../../include/tst_hip.h"
 
 void tst_set_error(const char* fmt, ...);
@@ -45,6 +46,15 @@ static inline int tst_after_launch(const char* what) {
         return TST_ERR_LAUNCH;
     }
     return TST_OK;
+}
+
+// Row counts, widths, vocabulary sizes and other counts are at most 2^31 - 1: the kernels count rows and columns in 32-bit
+// integers and build their grids from them.  Offsets in elements or bytes are formed in 64 bits, so leading dimensions and
+// whole buffers (rows x width) may be larger.  Every entry point checks this first.
+static inline bool tst_dims_ok(std::initializer_list<int64_t> sizes) {
+    for (int64_t v : sizes)
+        if (v > (int64_t)0x7fffffff) return false;
+    return true;
 }
 
 static inline bool tst_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
