@@ -277,3 +277,23 @@ def test_run_on_streams_returns_results_in_order_and_reraises(T):
     with pytest.raises(ValueError, match='from a job'):
         T.run_on_streams([lambda: 1, boom])
     assert T.run_on_streams([lambda: 7]) == [7] and T.run_on_streams([]) == []
+
+
+def test_run_on_streams_reuses_its_streams_so_cached_memory_does_not_grow(T):
+    """PyTorch caches freed blocks per stream: side streams that were new for every call reserved the jobs' buffers again every
+    time (65 GB per call for a config-4 batch, until the device was full).  Repeated calls reserve once; results handed to the
+    caller's stream stay valid while later calls reuse the side streams' blocks."""
+    def job(i):
+        a = torch.full((64 << 20,), float(i), device='cuda')        # 256 MB of work memory on the side stream
+        return (a[:1000] * 2).clone(), {'sum': a[:10].sum()}
+
+    reserved, kept = [], []
+    for it in range(5):
+        out = T.run_on_streams([(lambda i=i: job(i + 10 * it)) for i in range(3)])
+        kept.append(out)
+        torch.cuda.synchronize()
+        reserved.append(torch.cuda.memory_reserved())
+    assert reserved[4] == reserved[1], reserved
+    for it, out in enumerate(kept):
+        for i, (t, d) in enumerate(out):
+            assert float(t[0]) == 2.0 * (i + 10 * it) and float(d['sum']) == 10.0 * (i + 10 * it)

@@ -171,7 +171,34 @@ def cfg3(n_sent, bias=None):
                                                 'beam_size': beam}), n_sent)
 
 
-def cfg4(n_sent, bias=None, dtypes=('bf16', 'fp32')):
+class _Parts:
+    """The sentences dealt to `parts` independent InferenceStates that decode at the same time on streams of their own
+    (tst_amd.run_on_streams); outputs put back in order, counters summed."""
+
+    class _Loop:
+        steps_done = rows_stepped = 0
+
+    def __init__(self, make, z, parts):
+        self.parts, self.n = parts, z.shape[0]
+        self.states = [make(z[p::parts].contiguous()) for p in range(parts)]
+        self.loop = self._Loop()
+
+    def decode_packed(self):
+        outs = tst_amd.run_on_streams([st.decode_packed for st in self.states])
+        width = max(o[0].shape[1] for o in outs)
+        tok = torch.zeros((self.n, width), dtype=outs[0][0].dtype, device=outs[0][0].device)
+        lens = torch.empty(self.n, dtype=outs[0][1].dtype, device=tok.device)
+        score = torch.empty(self.n, dtype=outs[0][2].dtype, device=tok.device)
+        for p, (t, n, sc) in enumerate(outs):
+            tok[p::self.parts, :t.shape[1]] = t
+            lens[p::self.parts] = n
+            score[p::self.parts] = sc
+        self.loop.steps_done = max(st.loop.steps_done for st in self.states)
+        self.loop.rows_stepped = sum(st.loop.rows_stepped for st in self.states)
+        return tok, lens, score
+
+
+def cfg4(n_sent, bias=None, dtypes=('bf16', 'fp32'), parts=1):
     dev = torch.device('cuda', 0)
     V = 32000
     vocab = tst_amd.Vocab.synthetic(V)
@@ -180,9 +207,9 @@ def cfg4(n_sent, bias=None, dtypes=('bf16', 'fp32')):
     for dtype in dtypes:
         lm = tst_amd.TransformerLM(tst_amd.HP(hp), vocab, device=dev, dtype=dtype)
         lm.load_state_dict(synthetic.synthetic_state_dict(lm, 3, 5.0 if bias is None else bias, 2.0, seed=42))
-        run('cfg4 TransformerLM d=512 L=6 V=32000 beam=8 %s max_len=50' % dtype,
-            lambda: tst_amd.InferenceState({'model': lm, 'inputs': z, 'vocab': vocab, 'max_len': 50, 'beam_size': 8}), n_sent,
-            repeats=2)
+        make = lambda zz: tst_amd.InferenceState({'model': lm, 'inputs': zz, 'vocab': vocab, 'max_len': 50, 'beam_size': 8})   # noqa: E731
+        run('cfg4 TransformerLM d=512 L=6 V=32000 beam=8 %s max_len=50%s' % (dtype, '' if parts == 1 else ' (%d concurrent sub-batches)' % parts),
+            (lambda: make(z)) if parts == 1 else (lambda: _Parts(make, z, parts)), n_sent, repeats=2)
         del lm
         torch.cuda.empty_cache()
 
@@ -194,6 +221,7 @@ if __name__ == '__main__':
     ap.add_argument('--dtype', default=None, help='cfg4: only this dtype (bf16 or fp32)')
     ap.add_argument('--eos-bias', type=float, default=None, help='override the calibrated EOS bias (calibration runs)')
     ap.add_argument('--streams', type=int, default=0, help='cfg1: that many batches at a time, one host thread and HIP stream each')
+    ap.add_argument('--parts', type=int, default=1, help='cfg4: the batch as that many sub-batches decoded at the same time on streams')
     a = ap.parse_args()
     if a.which == 'cfg1' and a.streams > 0:
         cfg1_streams(a.sentences, a.streams, a.eos_bias)
@@ -202,4 +230,4 @@ if __name__ == '__main__':
     if a.which in ('cfg3', 'all'):
         cfg3(a.sentences, a.eos_bias)
     if a.which in ('cfg4', 'all'):
-        cfg4(a.sentences, a.eos_bias, ('bf16', 'fp32') if a.dtype is None else (a.dtype,))
+        cfg4(a.sentences, a.eos_bias, ('bf16', 'fp32') if a.dtype is None else (a.dtype,), a.parts)
