@@ -297,3 +297,44 @@ def test_run_on_streams_reuses_its_streams_so_cached_memory_does_not_grow(T):
     for it, out in enumerate(kept):
         for i, (t, d) in enumerate(out):
             assert float(t[0]) == 2.0 * (i + 10 * it) and float(d['sum']) == 10.0 * (i + 10 * it)
+
+
+def test_in_place_weight_edits_reach_the_kernels(T):
+    """The kernels read converted copies of the weights (transposed, concatenated, per-token tables) that are made once.  A
+    parameter edited in place after a decode (what an optimizer step over ``parameters()`` does between two validation passes,
+    /root/reference/src/trainers/transformer_mt_trainer.py:80-98) must reach the next decode: outputs equal those of a fresh
+    model loaded with the edited state."""
+    tmodel, model, vocab, encs, mask = mt_case(T, 300, 40, 9, 2.0, 6)
+    before, _ = decode(T, model, vocab, encs, mask, 12, 1)
+    names = list(model.decoder._params.keys())
+    params = dict(zip(names, model.decoder.parameters()))
+    g = torch.Generator().manual_seed(1)
+    for n in ('layers.0.self_attn.q.weight', 'layers.1.ff.w2.weight', 'out.weight'):
+        params[n].add_(0.05 * torch.randn(params[n].shape, generator=g).cuda())           # in place: same tensor objects
+    after, _ = decode(T, model, vocab, encs, mask, 12, 1)
+    fresh = T.Transformer(T.HP(R.mt_hp()), vocab, vocab)
+    fresh.load_state_dict(model.state_dict())
+    want, _ = decode(T, fresh, vocab, encs, mask, 12, 1)
+    assert after == want and after != before
+    # a GRU decoder with the per-token table of layer 0 and a bf16 language model (copies per arithmetic type)
+    tv = R.synthetic_vocab(90)
+    vg = T.Vocab.synthetic(90)
+    gru = T.RNNDecoder(64, 128, vg)
+    gru.load_state_dict(R.synthetic_init(R.RNNDecoder(64, 128, tv), 3, 1.0, 2.0, seed=3).state_dict())
+    z = torch.randn((30, 128), generator=torch.Generator().manual_seed(2)).cuda()
+
+    def run(m, **kw):
+        st = T.InferenceState(dict({'model': m, 'inputs': z, 'vocab': vg, 'max_len': 10}, **kw))
+        return [s.cpu().tolist() for s in st.inference()]
+    a = run(gru)
+    dict(zip(gru._params.keys(), gru.parameters()))['embed.weight'].mul_(-1.0)
+    b = run(gru)
+    gru2 = T.RNNDecoder(64, 128, vg)
+    gru2.load_state_dict(gru.state_dict())
+    assert b == run(gru2) and a != b
+    hp = dict(model_size=128, n_layers=2, n_heads=4, d_ff=256, pe_max_len=40)
+    lm = T.TransformerLM(T.HP(hp), vg, dtype='bf16')
+    lm.load_state_dict(R.synthetic_init(R.TransformerLM(R.HP(hp), tv), 3, 2.0, 2.0, seed=4).state_dict())
+    a = run(lm)
+    dict(zip(lm._params.keys(), lm.parameters()))['out.bias'][3] += 40.0                  # every sentence now ends at once
+    assert all(len(s) == 1 for s in run(lm)) and any(len(s) > 1 for s in a)

@@ -68,7 +68,10 @@ class TransformerLM(HipModule):
     # assigning None (load_state_dict, to) drops them all
     @property
     def _prepared(self):
-        return self.__dict__.setdefault('_prepared_by_dtype', {}).get(self.__dict__.get('dtype'))
+        store = self.__dict__.setdefault('_prepared_by_dtype', {})
+        if store and self.__dict__.get('_prep_token') != self._weights_token():     # a parameter was edited in place
+            store.clear()
+        return store.get(self.__dict__.get('dtype'))
 
     @_prepared.setter
     def _prepared(self, value):
@@ -77,6 +80,7 @@ class TransformerLM(HipModule):
             store.clear()
         else:
             store[self.dtype] = value
+            self.__dict__['_prep_token'] = self._weights_token()
 
     def prepared(self):
         """Weights in kernel layout: fp32 -> transposed [in, out]; bf16 -> as stored [out, in], rounded to bf16."""

@@ -42,6 +42,24 @@ class HipModule:
         self._params = OrderedDict()
         self._prepared = None
 
+    # The kernels read weights in their own layouts (transposed, concatenated, padded, bf16, per-token tables), made once by
+    # prepared() and kept here.  An in-place edit of a parameter tensor (an optimizer step over parameters(), p.copy_(...))
+    # bumps that tensor's version counter, which drops the kept copies, so the next call converts the edited weights.
+    def _weights_token(self):
+        return tuple(v._version for v in self._params.values())
+
+    @property
+    def _prepared(self):
+        d = self.__dict__
+        if d.get('_prep') is not None and d.get('_prep_token') != self._weights_token():
+            d['_prep'] = None
+        return d.get('_prep')
+
+    @_prepared.setter
+    def _prepared(self, value):
+        self.__dict__['_prep'] = value
+        self.__dict__['_prep_token'] = None if value is None else self._weights_token()
+
     def _add(self, name, shape, std=None, fill=None):
         if fill is not None:
             t = torch.full(shape, float(fill), dtype=torch.float32)
