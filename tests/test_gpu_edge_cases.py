@@ -338,3 +338,34 @@ def test_in_place_weight_edits_reach_the_kernels(T):
     a = run(lm)
     dict(zip(lm._params.keys(), lm.parameters()))['out.bias'][3] += 40.0                  # every sentence now ends at once
     assert all(len(s) == 1 for s in run(lm)) and any(len(s) > 1 for s in a)
+
+
+@pytest.mark.parametrize('mode', ['inference_mode', 'no_grad'])
+def test_whole_path_under_inference_mode_and_no_grad(T, mode):
+    """Callers wrap validation in ``torch.no_grad()`` or ``torch.inference_mode()``; tensors made under the latter keep no
+    version counter (reading it raises).  Building the model, loading weights, the encoder pass, the decode and an in-place
+    edit of the encoder outputs between the two all work there and give the outputs of the plain call."""
+    hp = R.mt_hp()
+    tv = R.synthetic_vocab(200)
+    tmodel = R.synthetic_init(R.Transformer(R.HP(hp), tv, tv), 3, 2.0, 2.0, seed=5)
+    vocab = T.Vocab.synthetic(200)
+    src = torch.from_numpy(np.random.RandomState(2).randint(4, 200, size=(23, 8))).cuda()
+
+    def run(edit):
+        model = T.Transformer(T.HP(hp), vocab, vocab)
+        model.load_state_dict(tmodel.state_dict())
+        encs, mask = model.encoder(src)
+        if edit:
+            encs.mul_(0.5)
+        st = T.InferenceState({'model': model.decoder, 'inputs': encs, 'enc_mask': mask, 'vocab': vocab, 'max_len': 9, 'beam_size': 3})
+        out = [s.cpu().tolist() for s in st.inference()]
+        names = list(model.decoder._params.keys())
+        dict(zip(names, model.decoder.parameters()))['out.bias'][3] += 40.0          # in place, under the same mode
+        st = T.InferenceState({'model': model.decoder, 'inputs': encs, 'enc_mask': mask, 'vocab': vocab, 'max_len': 9})
+        return out, [s.cpu().tolist() for s in st.inference()]
+    plain = run(False), run(True)
+    with getattr(torch, mode)():
+        inside = run(False), run(True)
+    assert inside == plain
+    assert plain[0][0] != plain[1][0]                       # the edit of the encoder outputs changed the decode
+    assert all(len(s) == 1 for s in plain[0][1])            # and the edited bias ended every sentence at once

@@ -10,7 +10,7 @@ import math
 import torch
 
 from . import kernels as K
-from .transformer import HP, HipModule, _t, sinusoid_table
+from .transformer import HP, HipModule, _t, sinusoid_table, tensor_version
 
 
 class TransformerEncoder(HipModule):
@@ -38,7 +38,8 @@ class TransformerEncoder(HipModule):
             self._add(p + 'ff.w2.bias', (d,), fill=0.0)
         self._add('ln.weight', (d,), fill=1.0)
         self._add('ln.bias', (d,), fill=0.0)
-        self._params['pe'] = sinusoid_table(hp.pe_max_len, d).to(self.device)
+        with torch.inference_mode(False):
+            self._params['pe'] = sinusoid_table(hp.pe_max_len, d).to(self.device)
 
     def prepared(self):
         if self._prepared is None:
@@ -100,6 +101,6 @@ class TransformerEncoder(HipModule):
         # every in-place edit, e.g. ``encs.add_(style)`` or ``enc_mask[..., j] = False``, after which the session repacks
         # from the tensors it is given)
         packed.rows = h
-        packed.versions = (encs._version, enc_mask._version)
+        packed.versions = (tensor_version(encs), tensor_version(enc_mask))    # None under torch.inference_mode(): the session repacks
         encs._tst_packed = enc_mask._tst_packed = packed
         return encs, enc_mask

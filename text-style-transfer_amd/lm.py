@@ -62,7 +62,8 @@ class TransformerLM(HipModule):
         self._add('ln.bias', (d,), fill=0.0)
         self._add('out.weight', (self.V, d), std=s)
         self._add('out.bias', (self.V,), fill=0.0)
-        self._params['pe'] = sinusoid_table(self.pe_max_len, d).to(self.device)
+        with torch.inference_mode(False):
+            self._params['pe'] = sinusoid_table(self.pe_max_len, d).to(self.device)
 
     # kernel-side weight copies are kept per arithmetic type, so switching back and forth converts nothing twice;
     # assigning None (load_state_dict, to) drops them all

@@ -34,6 +34,15 @@ def sinusoid_table(n_pos, d_model):
     return pe.to(torch.float32)
 
 
+def tensor_version(t):
+    """Version counter of a tensor (moves with every in-place edit), or None for tensors that keep none (tensors made under
+    ``torch.inference_mode()``): callers then assume nothing about the contents."""
+    try:
+        return t._version
+    except RuntimeError:
+        return None
+
+
 class HipModule:
     """Minimal parameter container with the ``nn.Module`` methods the reference's callers use."""
 
@@ -46,7 +55,7 @@ class HipModule:
     # prepared() and kept here.  An in-place edit of a parameter tensor (an optimizer step over parameters(), p.copy_(...))
     # bumps that tensor's version counter, which drops the kept copies, so the next call converts the edited weights.
     def _weights_token(self):
-        return tuple(v._version for v in self._params.values())
+        return tuple(tensor_version(v) for v in self._params.values())
 
     @property
     def _prepared(self):
@@ -61,11 +70,12 @@ class HipModule:
         self.__dict__['_prep_token'] = None if value is None else self._weights_token()
 
     def _add(self, name, shape, std=None, fill=None):
-        if fill is not None:
-            t = torch.full(shape, float(fill), dtype=torch.float32)
-        else:
-            t = torch.randn(shape, dtype=torch.float32) * std
-        self._params[name] = t.to(self.device)
+        with torch.inference_mode(False):      # parameters are ordinary tensors (with version counters) wherever the model is made
+            if fill is not None:
+                t = torch.full(shape, float(fill), dtype=torch.float32)
+            else:
+                t = torch.randn(shape, dtype=torch.float32) * std
+            self._params[name] = t.to(self.device)
 
     def state_dict(self):
         return OrderedDict((k, v.clone()) for k, v in self._params.items())
@@ -79,7 +89,8 @@ class HipModule:
             if k in sd:
                 if tuple(sd[k].shape) != tuple(self._params[k].shape):
                     raise ValueError('shape mismatch for %s: %s vs %s' % (k, tuple(sd[k].shape), tuple(self._params[k].shape)))
-                self._params[k] = sd[k].detach().to(device=self.device, dtype=torch.float32).contiguous().clone()
+                with torch.inference_mode(False):
+                    self._params[k] = sd[k].detach().to(device=self.device, dtype=torch.float32).contiguous().clone()
         self._prepared = None
         return self
 
@@ -94,7 +105,8 @@ class HipModule:
 
     def to(self, device):
         self.device = torch.device(device)
-        self._params = OrderedDict((k, v.to(self.device)) for k, v in self._params.items())
+        with torch.inference_mode(False):
+            self._params = OrderedDict((k, v.to(self.device)) for k, v in self._params.items())
         self._prepared = None
         return self
 
@@ -143,7 +155,8 @@ class TransformerDecoder(HipModule):
             raise ValueError('d_model / n_heads must be a multiple of 4')
         s = 1.0 / math.sqrt(d)
         self._add('embed.weight', (V, d), std=s)
-        self._params['pe'] = sinusoid_table(hp.pe_max_len, d).to(self.device)
+        with torch.inference_mode(False):
+            self._params['pe'] = sinusoid_table(hp.pe_max_len, d).to(self.device)
         for i in range(hp.n_layers):
             p = 'layers.%d.' % i
             for ln, att in (('ln1', 'self_attn'), ('ln2', 'cross_attn')):
@@ -248,7 +261,7 @@ class TransformerSession:
             raise ValueError('max_len %d exceeds pe_max_len %d' % (max_len, W['pe'].shape[0]))
         packed = getattr(encs, '_tst_packed', None)
         if (packed is None or packed is not getattr(enc_mask, '_tst_packed', None) or packed.rows.device != dev
-                or getattr(packed, 'versions', None) != (encs._version, enc_mask._version)):
+                or None in packed.versions or packed.versions != (tensor_version(encs), tensor_version(enc_mask))):
             packed = None     # not the untouched outputs of this package's encoder (other objects, or edited in place): pack here
         encs = encs.to(device=dev, dtype=torch.float32).contiguous()
         B, S, d = encs.shape
