@@ -1,5 +1,6 @@
 """GPU: the environment switches that route a decode step through alternative kernels (the row-tile chain kernels, the
-persistent vocabulary projection, the LayerNorm epilogue of the bf16 residual products) are read once per process, so each is
+persistent vocabulary projection, the LayerNorm epilogue of the bf16 residual products, the K = 256 products with the weights
+held in registers) are read once per process, so each is
 exercised in a child process: the same synthetic batches must come out token for token as in the default process."""
 import hashlib
 import json
@@ -39,13 +40,30 @@ z = (0.3 * torch.randn((600, 512), generator=torch.Generator().manual_seed(5))).
 st = tst_amd.InferenceState({'model': lm, 'inputs': z, 'vocab': vocab, 'max_len': 16, 'beam_size': 8})
 tok, lens, score = st.decode_packed()
 out['lm'] = hashlib.sha256(tok.cpu().numpy().tobytes() + lens.cpu().numpy().tobytes() + score.cpu().numpy().tobytes()).hexdigest()
+# the K = 256 layer products at row counts beyond the one-wave strips, with bias / relu / residual, rows no multiple of the tile
+from tst_amd import kernels as K
+g = torch.Generator(device='cuda').manual_seed(11)
+hsh = hashlib.sha256()
+for M, N, res, act in ((3300, 256, True, 0), (5001, 768, False, 0), (4100, 1024, False, 1), (20481, 256, True, 1), (9000, 512, False, 0)):
+    a = torch.randn((M, 256), device='cuda', generator=g)
+    w = torch.randn((256, N), device='cuda', generator=g) / 16
+    b = torch.randn(N, device='cuda', generator=g)
+    r = torch.randn((M, N), device='cuda', generator=g) if res else None
+    o = torch.full((M + 1, N), 7.0, device='cuda')
+    K.gemm(a, w, b, o, M, res=r, act=act)
+    assert (o[M] == 7.0).all()
+    hsh.update(o[:M].cpu().numpy().tobytes())
+    if res:                                         # in place: the output is the residual
+        K.gemm(a, w, b, r, M, res=r, act=act)
+        assert torch.equal(r, o[:M])
+out['gemm_k256'] = hsh.hexdigest()
 print('RESULT ' + json.dumps(out))
 ''' % ROOT
 
 
 def run_child(extra_env):
     env = dict(os.environ)
-    for k in ('TST_TFM_CHAIN', 'TST_VOCAB_VARIANT', 'TST_BF16_LN_FUSE'):
+    for k in ('TST_TFM_CHAIN', 'TST_VOCAB_VARIANT', 'TST_BF16_LN_FUSE', 'TST_GEMM_WREG'):
         env.pop(k, None)
     env.update(extra_env)
     p = subprocess.run([sys.executable, '-c', CHILD], env=env, capture_output=True, text=True, timeout=300)
@@ -61,6 +79,6 @@ def default_result():
 
 
 @pytest.mark.parametrize('env', [{'TST_TFM_CHAIN': '1'}, {'TST_VOCAB_VARIANT': '4'}, {'TST_VOCAB_VARIANT': '2'},
-                                 {'TST_BF16_LN_FUSE': '256'}, {'TST_TFM_CHAIN': '1', 'TST_VOCAB_VARIANT': '4'}])
+                                 {'TST_BF16_LN_FUSE': '256'}, {'TST_TFM_CHAIN': '1', 'TST_VOCAB_VARIANT': '4'}, {'TST_GEMM_WREG': '1'}])
 def test_alternative_kernels_give_the_default_outputs(default_result, env):
     assert run_child(env) == default_result

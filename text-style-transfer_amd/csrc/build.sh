@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")"
 OUT=../libtst_hip.so
 FLAGS="--offload-arch=gfx950 -O3 -fPIC -ffp-contract=off -std=c++17 -Wall -Wno-unused-result"
-UNITS="capi gemm_f32 gemm_f32_dma chain_f32 gemm_bf16 gru_fused rowops attn attn_mfma select gumbel step"
+UNITS="capi gemm_f32 gemm_f32_wreg gemm_f32_dma chain_f32 gemm_bf16 gru_fused rowops attn attn_mfma select gumbel step"
 pids=()
 for f in $UNITS; do
   if [ ! -f $f.o ] || [ $f.hip -nt $f.o ] || [ tst_common.h -nt $f.o ] || [ ../../include/tst_hip.h -nt $f.o ]; then

@@ -379,6 +379,11 @@ void launch_gemm_k32(const float* A, int64_t lda, const float* Wt, int64_t ldw, 
 #undef TST_K32_LAUNCH
 }
 
+bool tst_gemm_wreg_on() {
+    static const bool v = [] { const char* e = getenv("TST_GEMM_WREG"); return e != nullptr && e[0] == '1'; }();
+    return v;
+}
+
 bool tst_gemm_no_k32() {
     static const bool v = [] { const char* e = getenv("TST_GEMM_NO_K32"); return e != nullptr && e[0] == '1'; }();
     return v;
@@ -1010,6 +1015,8 @@ extern "C" int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, i
         launch_skinny<2>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
     else if (tiles16 <= 3072)
         launch_skinny<4>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
+    else if (tst_gemm_wreg_on() && tst_gemm_wreg_ok(M, N, K))
+        tst_launch_gemm_wreg(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, act, (hipStream_t)stream);
     else if (big_tiles >= 4096 && N >= 2048)
         launch_gemm<2, 4>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
     else if (big_tiles >= 640)

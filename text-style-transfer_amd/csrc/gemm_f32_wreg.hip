@@ -1,0 +1,136 @@
+// fp32 GEMM for the layer products of a d_model = 256 decoder at thousands of rows: C = epilogue(bias + A * Wt), K = 256.
+//
+// The 64 x 64 and 128 x 128 tile kernels of gemm_f32.hip read BOTH MFMA operands from LDS, one or two ds_read per
+// v_mfma_f32_32x32x2_f32, and stage the A panel once per 64 columns of C; operand delivery, not the matrix pipe, is what
+// holds them at 0.5-0.6 of the peak.  Here the WEIGHTS stay in registers: a wave owns 32 columns of C for the whole kernel
+// and keeps their 256 x 32 slab of Wt as the 128 B-operands of its MFMA chain (128 VGPRs), a workgroup of 8 waves owns 256
+// columns and walks over 32-row tiles of A.  Per tile the workgroup stages 32 whole rows of A (32 KB) ONCE into LDS, and a wave
+// reads its A operands with one ds_read_b128 per FOUR MFMAs: the row image is stored with the k of every group of eight
+// permuted to (0, 2, 4, 6 | 1, 3, 5, 7), so that the sixteen bytes a lane reads are the operands of four consecutive k-steps
+// (lane half h of step j takes k = 2 j + h).  Two tile buffers, one barrier per tile; the loads of the next tile are in
+// flight during the 128 MFMAs of the current one.
+//
+// Same arithmetic as every other fp32 product here: acc = bias[n]; for k ascending: acc = fma(A[m][k], Wt[k][n], acc),
+// then relu, then + residual.  C may alias the residual (each element is read and then written by the same lane).
+#include "tst_common.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+constexpr int WR_K = 256;          // reduction length
+constexpr int WR_BM = 32;          // rows of A per tile
+constexpr int WR_BN = 256;         // columns of C per workgroup: 8 waves x 32
+constexpr int WR_LDA = WR_K + 4;   // floats per LDS row: consecutive rows start 4 banks apart, so the 16-byte reads of 8 rows
+                                   // (one 128-byte LDS access) fall into different banks
+
+template <bool HAS_RES, bool RELU>
+__global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
+                                                               int64_t ldw, const float* __restrict__ bias, const float* res,
+                                                               int64_t ldr, float* C, int64_t ldc, int M, int n_tiles, int n_groups,
+                                                               int wg_per_group) {
+    __shared__ __attribute__((aligned(16))) float As[2][WR_BM * WR_LDA];
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int group = blockIdx.x % n_groups, slot = blockIdx.x / n_groups;
+    const int h = lane >> 5;
+    const int col = group * WR_BN + wave * 32 + (lane & 31);
+
+    // the wave's slab of the weights: w[j] = Wt[2 j + h][col], the B operand of k-step j (two 128-byte pieces of Wt per request)
+    float w[WR_K / 2];
+    {
+        const float* wp = W + (int64_t)h * ldw + col;
+#pragma unroll
+        for (int j = 0; j < WR_K / 2; ++j) w[j] = wp[(int64_t)(2 * j) * ldw];
+    }
+    const float b = bias != nullptr ? bias[col] : 0.0f;
+
+    // staging: wave v brings rows 4 v .. 4 v + 3 of a tile, lane l the floats 4 l .. 4 l + 3 of each (whole rows, 1 KB per request)
+    float4 st[4];
+    auto load_tile = [&](int tile) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int row = min(tile * WR_BM + wave * 4 + i, M - 1);
+            st[i] = *reinterpret_cast<const float4*>(A + (int64_t)row * lda + 4 * lane);
+        }
+    };
+    // lanes 2 g and 2 g + 1 hold k = 8 g .. 8 g + 7 of a row; they exchange two values each and write (0, 2, 4, 6) and (1, 3, 5, 7)
+    auto write_tile = [&](int buf) {
+        const bool odd = (lane & 1) != 0;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float4 v = st[i];
+            const float r0 = lane_xor<1>(odd ? v.x : v.y);
+            const float r1 = lane_xor<1>(odd ? v.z : v.w);
+            const float4 o = odd ? make_float4(r0, r1, v.y, v.w) : make_float4(v.x, v.z, r0, r1);
+            *reinterpret_cast<float4*>(&As[buf][(wave * 4 + i) * WR_LDA + 4 * lane]) = o;
+        }
+    };
+
+    int tile = slot;
+    if (tile < n_tiles) {
+        load_tile(tile);
+        write_tile(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (; tile < n_tiles; tile += wg_per_group) {
+        const int nxt = tile + wg_per_group;
+        if (nxt < n_tiles) load_tile(nxt);
+        const int row0 = tile * WR_BM + 4 * h;     // accumulator register r holds row row0 + (r & 3) + 8 (r >> 2), column col
+        float rv[16];
+        if (HAS_RES) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = min(row0 + (r & 3) + 8 * (r >> 2), M - 1);
+                rv[r] = res[(int64_t)row * ldr + col];
+            }
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = b;
+        const float* ap = &As[buf][(lane & 31) * WR_LDA + 4 * h];
+        float4 a_cur = *reinterpret_cast<const float4*>(ap), a_nxt = a_cur;
+#pragma unroll
+        for (int q = 0; q < WR_K / 8; ++q) {
+            if (q + 1 < WR_K / 8) a_nxt = *reinterpret_cast<const float4*>(ap + (q + 1) * 8);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, w[4 * q + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, w[4 * q + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, w[4 * q + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, w[4 * q + 3], acc, 0, 0, 0);
+            a_cur = a_nxt;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2);
+            float v = acc[r];
+            if (RELU) v = v > 0.0f ? v : 0.0f;
+            if (HAS_RES) v = v + rv[r];
+            if (row < M) C[(int64_t)row * ldc + col] = v;
+        }
+        if (nxt < n_tiles) write_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
+}  // namespace
+
+// Shapes the kernel takes: K = 256 and whole groups of 256 columns.
+bool tst_gemm_wreg_ok(int64_t M, int64_t N, int64_t K) { return K == WR_K && N >= WR_BN && N % WR_BN == 0 && N <= 256 * WR_BN / 8 && M >= 1; }
+
+void tst_launch_gemm_wreg(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res, int64_t ldr,
+                          float* C, int64_t ldc, int64_t M, int64_t N, int act, hipStream_t st) {
+    const int n_groups = (int)(N / WR_BN);
+    const int n_tiles = (int)((M + WR_BM - 1) / WR_BM);
+    const int wg_per_group = n_tiles < 256 / n_groups ? n_tiles : 256 / n_groups;      // one workgroup per CU
+    const dim3 grid((unsigned)(n_groups * wg_per_group));
+#define TST_WREG_LAUNCH(HR, RL)                                                                                                        \
+    hipLaunchKernelGGL((gemm_f32_wreg_kernel<HR, RL>), grid, dim3(512), 0, st, A, lda, Wt, ldw, bias, res, ldr, C, ldc, (int)M, n_tiles, \
+                       n_groups, wg_per_group)
+    if (res != nullptr) {
+        if (act == 1) TST_WREG_LAUNCH(true, true); else TST_WREG_LAUNCH(true, false);
+    } else {
+        if (act == 1) TST_WREG_LAUNCH(false, true); else TST_WREG_LAUNCH(false, false);
+    }
+#undef TST_WREG_LAUNCH
+}

@@ -1,5 +1,6 @@
 """Microbenchmark of tst_gemm_mfma_f32 on the layer products of the transformer-mt base model (HIP events, random data).
-Usage: python tools/bench_gemm_layers.py [rows ...]"""
+Usage: [REPS=n] python tools/bench_gemm_layers.py [rows ...]   (REPS launches between the two events of a timing: 1 includes the
+cost of starting a launch on an idle GPU, 10 or more show the kernel as it runs inside a step)"""
 import os
 import sys
 
@@ -13,6 +14,9 @@ SHAPES = [('o-proj +res', 256, 256, True, 0), ('cross-q', 256, 256, False, 0), (
           ('ff1 relu', 1024, 256, False, 1), ('ff2 +res', 256, 1024, True, 0)]
 
 
+REPS = int(os.environ.get('REPS', '1'))
+
+
 def med(fn, n=15):
     for _ in range(3):
         fn()
@@ -20,8 +24,11 @@ def med(fn, n=15):
     ts = []
     for _ in range(n):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(); fn(); e1.record(); torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
+        e0.record()
+        for _ in range(REPS):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ts.append(e0.elapsed_time(e1) / REPS)
     return sorted(ts)[len(ts) // 2]
 
 
