@@ -89,16 +89,24 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __re
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = b;
         const float* ap = &As[buf][(lane & 31) * WR_LDA + 4 * h];
-        float4 a_cur = *reinterpret_cast<const float4*>(ap), a_nxt = a_cur;
+        // operands of the k-steps 4 q .. 4 q + 3 are requested two groups (eight MFMAs) ahead; the scheduling barriers keep the
+        // requests where they are written (left alone, the compiler moves every read down to just before its first use)
+        float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 8), a2 = a1;
 #pragma unroll
         for (int q = 0; q < WR_K / 8; ++q) {
-            if (q + 1 < WR_K / 8) a_nxt = *reinterpret_cast<const float4*>(ap + (q + 1) * 8);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.x, w[4 * q + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.y, w[4 * q + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.z, w[4 * q + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur.w, w[4 * q + 3], acc, 0, 0, 0);
-            a_cur = a_nxt;
+            if (q + 2 < WR_K / 8) a2 = *reinterpret_cast<const float4*>(ap + (q + 2) * 8);
+            __builtin_amdgcn_sched_barrier(0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, w[4 * q + 0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, w[4 * q + 1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, w[4 * q + 2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, w[4 * q + 3], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            a0 = a1;
+            a1 = a2;
         }
+        // the next tile goes to LDS BEFORE this tile's results are stored: the wait for its loads (requested a whole tile ago)
+        // must not have the stores in front of it, or every tile would end with a wait for their completion
+        if (nxt < n_tiles) write_tile(buf ^ 1);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = row0 + (r & 3) + 8 * (r >> 2);
@@ -107,8 +115,9 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __re
             if (HAS_RES) v = v + rv[r];
             if (row < M) C[(int64_t)row * ldc + col] = v;
         }
-        if (nxt < n_tiles) write_tile(buf ^ 1);
-        __syncthreads();
+        // a barrier over LDS only (__syncthreads() would also wait for the stores above to complete)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
         buf ^= 1;
     }
 }
