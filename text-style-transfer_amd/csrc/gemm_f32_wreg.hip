@@ -113,7 +113,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __re
             float v = acc[r];
             if (RELU) v = v > 0.0f ? v : 0.0f;
             if (HAS_RES) v = v + rv[r];
+#if !defined(WR_VARIANT)
             if (row < M) C[(int64_t)row * ldc + col] = v;
+#elif WR_VARIANT == 1      // ablation build: (practically) no stores; every variant keeps the row guard
+            if (row < M && v == 12345.678f) C[(int64_t)row * ldc + col] = v;
+#elif WR_VARIANT == 3      // ablation build: nontemporal stores
+            if (row < M) __builtin_nontemporal_store(v, &C[(int64_t)row * ldc + col]);
+#endif
         }
         // a barrier over LDS only (__syncthreads() would also wait for the stores above to complete)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -125,7 +131,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __re
 }  // namespace
 
 // Shapes the kernel takes: K = 256 and whole groups of 256 columns.
-bool tst_gemm_wreg_ok(int64_t M, int64_t N, int64_t K) { return K == WR_K && N >= WR_BN && N % WR_BN == 0 && N <= 256 * WR_BN / 8 && M >= 1; }
+bool tst_gemm_wreg_ok(int64_t M, int64_t N, int64_t K) { return K == WR_K && N >= WR_BN && N % WR_BN == 0 && N <= 256 * WR_BN && M >= 1; }
 
 void tst_launch_gemm_wreg(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res, int64_t ldr,
                           float* C, int64_t ldc, int64_t M, int64_t N, int act, hipStream_t st) {
