@@ -407,8 +407,8 @@ def main():
                 'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MATRIX_PEAK_TFLOPS, 'unit': 'TFLOP/s',
                 'frac': achieved / FP32_MATRIX_PEAK_TFLOPS, 'traffic': traffic,
                 'traffic_source': 'rocprofv3 --pmc passes of this command, committed under profiles/ (not collected in this run)',
-                'kernel': 'gemm_f32_dma_kernel (vocabulary projection [rows,256]x[256,32000], fp32 MFMA, operands by LDS-DMA; '
-                          'gemm_f32_kernel for launches under 2048 rows)',
+                'kernel': 'gemm_f32_wreg_kernel (vocabulary projection [rows,256]x[256,32000], fp32 MFMA, the weights held in registers, '
+                          'A tiles through LDS; gemm_f32_kernel for launches under 1024 rows)',
                 'launches': gemm_launches, 'avg_launch_ms': gemm_ms / max(1, gemm_launches),
                 'share_of_batch_time': gemm_ms / batch_ms,
                 'pass': 'separate event-timed pass over one batch after the timed region (HIP events on the launch stream)'}

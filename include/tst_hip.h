@@ -44,7 +44,9 @@ extern "C" {
  * tst_embed_posadd_rows_f32 (additions only);
  * 107 = 106 + tst_vocab_argmax_ok, tst_ln_vocab_argmax_f32, tst_tfm_step.argmax_keys, tst_select_step.am_keys /
  * n_alive_host (the structs grew at their ends);
- * 108 = 107 + tst_gru_cell_fused_tab_f32, tst_gru_cell_step_tab_f32, tst_gru_step.gi_tab / ld_gi_tab. */
+ * 108 = 107 + tst_gru_cell_fused_tab_f32, tst_gru_cell_step_tab_f32, tst_gru_step.gi_tab / ld_gi_tab;
+ * 109 = 108 + TST_WREG_MIN_ROWS (no new entry point: tst_tfm_step_run picks another kernel for the vocabulary projection at d = 256;
+ * counts beyond 2^31 - 1 are refused by every entry point). */
 int tst_version(void);
 /* Message of the last error on the calling thread (host pointer, valid until the next failing call). */
 const char* tst_last_error(void);
@@ -453,7 +455,9 @@ typedef struct tst_tfm_step {
     const tst_tfm_layer* layers;          /* host array of n_layers */
     float* ht;              /* fp32 only, optional: [d][ld_ht] k-major copy target of the final LayerNorm.  When set and the
                                step has at least TST_DMA_MIN_ROWS rows, the final LayerNorm writes here (tst_layernorm_t_f32)
-                               and the vocabulary projection is tst_gemm_dma_f32; h is then not written.  Same logits. */
+                               and the vocabulary projection is tst_gemm_dma_f32; h is then not written.  Same logits.
+                               Not used at d = 256, where steps of at least TST_WREG_MIN_ROWS rows project from h with the
+                               weights held in registers (same logits again, faster; a host need not provide ht there). */
     int64_t ld_ht;          /* >= slab_rows rounded up to a multiple of 128 */
     float* part;            /* bf16 only, optional: [ceil(slab_rows / 32)][n_slices][64] statistics of the logits.  When set and
                                tst_vocab_stats_ok(rows, V, d), the vocabulary projection is tst_vocabproj_stats_bf16 and
@@ -466,6 +470,7 @@ typedef struct tst_tfm_step {
                                set fails with TST_ERR_UNSUPPORTED. */
 } tst_tfm_step;
 #define TST_DMA_MIN_ROWS 2048
+#define TST_WREG_MIN_ROWS 1024
 
 #define TST_STEP_EMBED 1   /* x = emb[tok] * scale + pe[t] (+ z[sent]); without it x must hold the embeddings */
 #define TST_STEP_LAYERS 2  /* the layer stack and the final LayerNorm (into h) */

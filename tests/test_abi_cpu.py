@@ -30,7 +30,7 @@ def test_binding_covers_header_and_version():
     import tst_amd
     from tst_amd import _lib
     assert sorted(_lib.EXPORTS) == declared_symbols()
-    assert tst_amd.version() == 108
+    assert tst_amd.version() == 109
 
 
 def test_argument_errors_are_reported_not_crashed():

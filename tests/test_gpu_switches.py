@@ -1,7 +1,8 @@
 """GPU: the environment switches that route a decode step through alternative kernels (the row-tile chain kernels, the
 persistent vocabulary projection, the LayerNorm epilogue of the bf16 residual products, the K = 256 products with the weights
 held in registers) are read once per process, so each is
-exercised in a child process: the same synthetic batches must come out token for token as in the default process."""
+exercised in a child process: the same synthetic batches must come out token for token as in the default process (whose
+vocabulary projection at d_model 256 is the weights-in-registers kernel; TST_VOCAB_VARIANT=3 is the LDS-DMA kernel)."""
 import hashlib
 import json
 import os
@@ -44,7 +45,7 @@ out['lm'] = hashlib.sha256(tok.cpu().numpy().tobytes() + lens.cpu().numpy().toby
 from tst_amd import kernels as K
 g = torch.Generator(device='cuda').manual_seed(11)
 hsh = hashlib.sha256()
-for M, N, res, act in ((3300, 256, True, 0), (5001, 768, False, 0), (4100, 1024, False, 1), (20481, 256, True, 1), (9000, 512, False, 0)):
+for M, N, res, act in ((3300, 256, True, 0), (5001, 768, False, 0), (4100, 1024, False, 1), (20481, 256, True, 1), (9000, 512, False, 0), (4000, 300, True, 0), (3500, 40, False, 1)):
     a = torch.randn((M, 256), device='cuda', generator=g)
     w = torch.randn((256, N), device='cuda', generator=g) / 16
     b = torch.randn(N, device='cuda', generator=g)
@@ -79,6 +80,7 @@ def default_result():
 
 
 @pytest.mark.parametrize('env', [{'TST_TFM_CHAIN': '1'}, {'TST_VOCAB_VARIANT': '4'}, {'TST_VOCAB_VARIANT': '2'},
-                                 {'TST_BF16_LN_FUSE': '256'}, {'TST_TFM_CHAIN': '1', 'TST_VOCAB_VARIANT': '4'}, {'TST_GEMM_WREG': '1'}])
+                                 {'TST_BF16_LN_FUSE': '256'}, {'TST_TFM_CHAIN': '1', 'TST_VOCAB_VARIANT': '4'}, {'TST_GEMM_WREG': '1'}, {'TST_VOCAB_VARIANT': '3'},
+                                 {'TST_VOCAB_VARIANT': '3', 'TST_GEMM_WREG': '1'}])
 def test_alternative_kernels_give_the_default_outputs(default_result, env):
     assert run_child(env) == default_result

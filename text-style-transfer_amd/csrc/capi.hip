@@ -11,6 +11,6 @@ void tst_set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-extern "C" int tst_version(void) { return 108; }
+extern "C" int tst_version(void) { return 109; }
 
 extern "C" const char* tst_last_error(void) { return g_err; }

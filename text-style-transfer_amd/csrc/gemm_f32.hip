@@ -1016,7 +1016,7 @@ extern "C" int tst_gemm_mfma_f32(const float* A, int64_t lda, const float* Wt, i
     else if (tiles16 <= 3072)
         launch_skinny<4>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
     else if (tst_gemm_wreg_on() && tst_gemm_wreg_ok(M, N, K))
-        tst_launch_gemm_wreg(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, act, (hipStream_t)stream);
+        tst_launch_gemm_wreg(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, act, 0, (hipStream_t)stream);
     else if (big_tiles >= 4096 && N >= 2048)
         launch_gemm<2, 4>(A, lda, Wt, ldw, bias, res, ldr, C, ldc, M, N, K, act, (hipStream_t)stream);
     else if (big_tiles >= 640)

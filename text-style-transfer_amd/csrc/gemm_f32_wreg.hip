@@ -24,25 +24,27 @@ constexpr int WR_BN = 256;         // columns of C per workgroup: 8 waves x 32
 constexpr int WR_LDA = WR_K + 4;   // floats per LDS row: consecutive rows start 4 banks apart, so the 16-byte reads of 8 rows
                                    // (one 128-byte LDS access) fall into different banks
 
-template <bool HAS_RES, bool RELU>
+template <bool HAS_RES, bool RELU, bool NT>
 __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
                                                                int64_t ldw, const float* __restrict__ bias, const float* res,
-                                                               int64_t ldr, float* C, int64_t ldc, int M, int n_tiles, int n_groups,
-                                                               int wg_per_group) {
+                                                               int64_t ldr, float* C, int64_t ldc, int M, int N, int n_tiles,
+                                                               int n_groups, int wg_per_group) {
     __shared__ __attribute__((aligned(16))) float As[2][WR_BM * WR_LDA];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int group = blockIdx.x % n_groups, slot = blockIdx.x / n_groups;
     const int h = lane >> 5;
     const int col = group * WR_BN + wave * 32 + (lane & 31);
+    const bool col_ok = col < N;                    // the last group of a width that is no multiple of 256 has idle columns
+    const int lcol = col_ok ? col : N - 1;          // they load what the last column loads and store nothing
 
     // the wave's slab of the weights: w[j] = Wt[2 j + h][col], the B operand of k-step j (two 128-byte pieces of Wt per request)
     float w[WR_K / 2];
     {
-        const float* wp = W + (int64_t)h * ldw + col;
+        const float* wp = W + (int64_t)h * ldw + lcol;
 #pragma unroll
         for (int j = 0; j < WR_K / 2; ++j) w[j] = wp[(int64_t)(2 * j) * ldw];
     }
-    const float b = bias != nullptr ? bias[col] : 0.0f;
+    const float b = bias != nullptr ? bias[lcol] : 0.0f;
 
     // staging: wave v brings rows 4 v .. 4 v + 3 of a tile, lane l the floats 4 l .. 4 l + 3 of each (whole rows, 1 KB per request)
     float4 st[4];
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __re
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = min(row0 + (r & 3) + 8 * (r >> 2), M - 1);
-                rv[r] = res[(int64_t)row * ldr + col];
+                rv[r] = res[(int64_t)row * ldr + lcol];
             }
         }
         f32x16 acc;
@@ -114,11 +116,12 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __re
             if (RELU) v = v > 0.0f ? v : 0.0f;
             if (HAS_RES) v = v + rv[r];
 #if !defined(WR_VARIANT)
-            if (row < M) C[(int64_t)row * ldc + col] = v;
-#elif WR_VARIANT == 1      // ablation build: (practically) no stores; every variant keeps the row guard
-            if (row < M && v == 12345.678f) C[(int64_t)row * ldc + col] = v;
-#elif WR_VARIANT == 3      // ablation build: nontemporal stores
-            if (row < M) __builtin_nontemporal_store(v, &C[(int64_t)row * ldc + col]);
+            if (row < M && col_ok) {
+                if (NT) __builtin_nontemporal_store(v, &C[(int64_t)row * ldc + col]);
+                else C[(int64_t)row * ldc + col] = v;
+            }
+#elif WR_VARIANT == 1      // ablation build: (practically) no stores; every variant keeps the guards
+            if (row < M && col_ok && v == 12345.678f) C[(int64_t)row * ldc + col] = v;
 #endif
         }
         // a barrier over LDS only (__syncthreads() would also wait for the stores above to complete)
@@ -130,22 +133,24 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __re
 
 }  // namespace
 
-// Shapes the kernel takes: K = 256 and whole groups of 256 columns.
-bool tst_gemm_wreg_ok(int64_t M, int64_t N, int64_t K) { return K == WR_K && N >= WR_BN && N % WR_BN == 0 && N <= 256 * WR_BN && M >= 1; }
+// Shapes the kernel takes: K = 256, any width (the last group of 256 columns may be partial), up to 256 groups.
+bool tst_gemm_wreg_ok(int64_t M, int64_t N, int64_t K) { return K == WR_K && N >= 1 && (N + WR_BN - 1) / WR_BN <= 256 && M >= 1; }
 
+// nontemporal: the results leave the caches as they are written (logits that another kernel reads once, later)
 void tst_launch_gemm_wreg(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res, int64_t ldr,
-                          float* C, int64_t ldc, int64_t M, int64_t N, int act, hipStream_t st) {
-    const int n_groups = (int)(N / WR_BN);
+                          float* C, int64_t ldc, int64_t M, int64_t N, int act, int nontemporal, hipStream_t st) {
+    const int n_groups = (int)((N + WR_BN - 1) / WR_BN);
     const int n_tiles = (int)((M + WR_BM - 1) / WR_BM);
     const int wg_per_group = n_tiles < 256 / n_groups ? n_tiles : 256 / n_groups;      // one workgroup per CU
     const dim3 grid((unsigned)(n_groups * wg_per_group));
-#define TST_WREG_LAUNCH(HR, RL)                                                                                                        \
-    hipLaunchKernelGGL((gemm_f32_wreg_kernel<HR, RL>), grid, dim3(512), 0, st, A, lda, Wt, ldw, bias, res, ldr, C, ldc, (int)M, n_tiles, \
-                       n_groups, wg_per_group)
-    if (res != nullptr) {
-        if (act == 1) TST_WREG_LAUNCH(true, true); else TST_WREG_LAUNCH(true, false);
+#define TST_WREG_LAUNCH(HR, RL, NT)                                                                                                        \
+    hipLaunchKernelGGL((gemm_f32_wreg_kernel<HR, RL, NT>), grid, dim3(512), 0, st, A, lda, Wt, ldw, bias, res, ldr, C, ldc, (int)M, (int)N, \
+                       n_tiles, n_groups, wg_per_group)
+    if (nontemporal && res == nullptr && act != 1) TST_WREG_LAUNCH(false, false, true);
+    else if (res != nullptr) {
+        if (act == 1) TST_WREG_LAUNCH(true, true, false); else TST_WREG_LAUNCH(true, false, false);
     } else {
-        if (act == 1) TST_WREG_LAUNCH(false, true); else TST_WREG_LAUNCH(false, false);
+        if (act == 1) TST_WREG_LAUNCH(false, true, false); else TST_WREG_LAUNCH(false, false, false);
     }
 #undef TST_WREG_LAUNCH
 }

@@ -38,9 +38,13 @@ struct StepCtx {
 // TST_TFM_CHAIN=1 in the environment (measurements): large fp32 steps of a d_model = 256 decoder with cross-attention run the
 // residual product -> LayerNorm -> next product chains as one kernel each (tst_chain_f32).  Same results; measured slower
 // than the separate launches at most row counts (a 64-row tile per CU: rounds of 16384 rows), hence off by default.
-// TST_VOCAB_VARIANT=<n> in the environment (measurements): the tst_gemm_dma_f32 variant of the vocabulary projection
+// The fp32 vocabulary projection of a large step.  d_model = 256: the kernel that holds the weights in registers
+// (gemm_f32_wreg.hip; row-major final LayerNorm; 124-126 TFLOP/s inside the decode loop) from TST_WREG_MIN_ROWS rows on.  Other
+// widths: the final LayerNorm written k-major and both operands staged by LDS-DMA (tst_gemm_dma_f32, variant 3; 118-120 TFLOP/s
+// at d_model 256) from TST_DMA_MIN_ROWS rows on.  TST_VOCAB_VARIANT=<n> in the environment (measurements): 0..4 = that
+// tst_gemm_dma_f32 variant for every width, 5 = the default.
 int tst_vocab_variant() {
-    static const int v = [] { const char* e = getenv("TST_VOCAB_VARIANT"); return (e != nullptr && e[0] >= '0' && e[0] <= '4') ? e[0] - '0' : 3; }();
+    static const int v = [] { const char* e = getenv("TST_VOCAB_VARIANT"); return (e != nullptr && e[0] >= '0' && e[0] <= '5') ? e[0] - '0' : 5; }();
     return v;
 }
 
@@ -84,7 +88,9 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
     const bool keys_out = m->argmax_keys != nullptr;
     TST_REQUIRE(!keys_out || (!c.bf16 && phases == (TST_STEP_EMBED | TST_STEP_LAYERS | TST_STEP_VOCAB) && tst_vocab_argmax_ok(R, m->V, d)),
                 TST_ERR_UNSUPPORTED, "tst_tfm_step_run: argmax_keys needs fp32, all three phases and a shape tst_vocab_argmax_ok accepts");
-    const bool dma_vocab = !keys_out && !c.bf16 && m->ht != nullptr && R >= TST_DMA_MIN_ROWS && d % 16 == 0 && d <= 512;
+    const bool wreg_vocab = !keys_out && !c.bf16 && tst_vocab_variant() == 5 && !tst_tfm_chain() && R >= TST_WREG_MIN_ROWS &&
+                            tst_gemm_wreg_ok(R, m->V, d);
+    const bool dma_vocab = !wreg_vocab && !keys_out && !c.bf16 && m->ht != nullptr && R >= TST_DMA_MIN_ROWS && d % 16 == 0 && d <= 512;
     TST_REQUIRE(!dma_vocab || (m->ld_ht % 4 == 0 && m->ld_ht >= (R + 127) / 128 * 128), TST_ERR_ARG,
                 "tst_tfm_step_run: ld_ht must be a multiple of 4 and at least the rows rounded up to 128");
 
@@ -195,9 +201,13 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
         if (keys_out)
             TST_TRY(tst_ln_vocab_argmax_f32(m->x, m->ln_g, m->ln_b, m->eps, (const float*)m->wout, m->ld_wout, m->bout, m->argmax_keys, R, m->V,
                                             d, stream));
-        else if (dma_vocab)
+        else if (wreg_vocab) {
+            tst_launch_gemm_wreg((const float*)m->h, d, (const float*)m->wout, m->ld_wout, m->bout, nullptr, 0, (float*)m->logits, m->ld_logits, R,
+                                 m->V, 0, 1, (hipStream_t)stream);
+            TST_TRY(tst_after_launch("tst_tfm_step_run: vocabulary projection"));
+        } else if (dma_vocab)
             TST_TRY(tst_gemm_dma_f32(m->ht, m->ld_ht, (const float*)m->wout, m->ld_wout, m->bout, (float*)m->logits, m->ld_logits, R, m->V, d,
-                                     tst_vocab_variant(), stream));   // nontemporal stores: the logits leave the caches before they are read
+                                     tst_vocab_variant() == 5 ? 3 : tst_vocab_variant(), stream));   // nontemporal stores: the logits leave the caches before they are read
         else if (c.bf16 && m->part != nullptr && tst_vocab_stats_ok(R, m->V, d))
             // the selection pass of a beam search reads these statistics instead of the rows (tst_select_step_run)
             TST_TRY(tst_vocabproj_stats_bf16(m->h, d, m->wout, m->ld_wout, m->bout, m->logits, m->ld_logits, R, m->V, d, m->part,

@@ -29,7 +29,7 @@ int tst_embed_posadd_clear_f32(const int32_t* tok, const float* emb, const float
 // gemm_f32_wreg.hip: the K = 256 product with the weights held in registers (used by tst_gemm_mfma_f32)
 bool tst_gemm_wreg_ok(int64_t M, int64_t N, int64_t K);
 void tst_launch_gemm_wreg(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res, int64_t ldr,
-                          float* C, int64_t ldc, int64_t M, int64_t N, int act, hipStream_t st);
+                          float* C, int64_t ldc, int64_t M, int64_t N, int act, int nontemporal, hipStream_t st);
 
 // attn_mfma.hip: the matrix-core cross-attention of beam groups (used by tst_attn_cross_group_f32)
 int tst_cross_mfma_ok(int64_t S, int64_t dh, int64_t group);

@@ -11,6 +11,7 @@ from ._lib import call, STEP_EMBED, STEP_LAYERS, STEP_VOCAB, STEP_FUSED_CELL  # 
 
 
 DMA_MIN_ROWS = 2048   # TST_DMA_MIN_ROWS of include/tst_hip.h
+WREG_MIN_ROWS = 1024  # TST_WREG_MIN_ROWS
 
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None)
 
