@@ -1,14 +1,15 @@
-// fp32 GEMM for the layer products of a d_model = 256 decoder at thousands of rows: C = epilogue(bias + A * Wt), K = 256.
+// fp32 products with K = 256 (d_model of the transformer-mt decoder) at a thousand rows and more: C = epilogue(bias + A * Wt).
+// This is the vocabulary projection of those models' decode steps (tst_tfm_step_run); tst_gemm_mfma_f32 uses it for the layer
+// products only under TST_GEMM_WREG=1 (measured equal end to end there).
 //
-// The 64 x 64 and 128 x 128 tile kernels of gemm_f32.hip read BOTH MFMA operands from LDS, one or two ds_read per
-// v_mfma_f32_32x32x2_f32, and stage the A panel once per 64 columns of C; operand delivery, not the matrix pipe, is what
-// holds them at 0.5-0.6 of the peak.  Here the WEIGHTS stay in registers: a wave owns 32 columns of C for the whole kernel
-// and keeps their 256 x 32 slab of Wt as the 128 B-operands of its MFMA chain (128 VGPRs), a workgroup of 8 waves owns 256
-// columns and walks over 32-row tiles of A.  Per tile the workgroup stages 32 whole rows of A (32 KB) ONCE into LDS, and a wave
-// reads its A operands with one ds_read_b128 per FOUR MFMAs: the row image is stored with the k of every group of eight
-// permuted to (0, 2, 4, 6 | 1, 3, 5, 7), so that the sixteen bytes a lane reads are the operands of four consecutive k-steps
-// (lane half h of step j takes k = 2 j + h).  Two tile buffers, one barrier per tile; the loads of the next tile are in
-// flight during the 128 MFMAs of the current one.
+// The tile kernels of gemm_f32.hip and gemm_f32_dma.hip read BOTH MFMA operands from LDS and stage the A panel once per 64-256
+// columns of C.  Here the WEIGHTS stay in registers: a wave owns 32 columns of C for the whole kernel and keeps their 256 x 32
+// slab of Wt as the 128 B-operands of its MFMA chain (128 VGPRs); a workgroup of 8 waves owns 256 columns and walks over 32-row
+// tiles of A (with V = 32000: 125 column groups x 2 workgroups, ~245 tiles each, so the slab is loaded once per ~245 tiles).  Per
+// tile the workgroup stages 32 whole rows of A (32 KB) once into LDS, and a wave reads its A operands with one ds_read_b128 per
+// FOUR MFMAs: the row image is stored with the k of every group of eight permuted to (0, 2, 4, 6 | 1, 3, 5, 7), so that the sixteen
+// bytes a lane reads are the operands of four consecutive k-steps (lane half h of step j takes k = 2 j + h).  Two tile buffers,
+// one LDS-only barrier per tile; the loads of the next tile are in flight during the 128 MFMAs of the current one.
 //
 // Same arithmetic as every other fp32 product here: acc = bias[n]; for k ascending: acc = fma(A[m][k], Wt[k][n], acc),
 // then relu, then + residual.  C may alias the residual (each element is read and then written by the same lane).
@@ -115,14 +116,10 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __re
             float v = acc[r];
             if (RELU) v = v > 0.0f ? v : 0.0f;
             if (HAS_RES) v = v + rv[r];
-#if !defined(WR_VARIANT)
             if (row < M && col_ok) {
                 if (NT) __builtin_nontemporal_store(v, &C[(int64_t)row * ldc + col]);
                 else C[(int64_t)row * ldc + col] = v;
             }
-#elif WR_VARIANT == 1      // ablation build: (practically) no stores; every variant keeps the guards
-            if (row < M && col_ok && v == 12345.678f) C[(int64_t)row * ldc + col] = v;
-#endif
         }
         // a barrier over LDS only (__syncthreads() would also wait for the stores above to complete)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
