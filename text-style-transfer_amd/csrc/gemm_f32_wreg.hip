@@ -124,6 +124,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __re
         // a barrier over LDS only (__syncthreads() would also wait for the stores above to complete)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");     // no LDS read of the next tile may be moved in front of the barrier
         buf ^= 1;
     }
 }
