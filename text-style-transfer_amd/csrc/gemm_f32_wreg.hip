@@ -14,6 +14,7 @@
 // Same arithmetic as every other fp32 product here: acc = bias[n]; for k ascending: acc = fma(A[m][k], Wt[k][n], acc),
 // then relu, then + residual.  C may alias the residual (each element is read and then written by the same lane).
 #include "tst_common.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -25,12 +26,16 @@ constexpr int WR_BN = 256;         // columns of C per workgroup: 8 waves x 32
 constexpr int WR_LDA = WR_K + 4;   // floats per LDS row: consecutive rows start 4 banks apart, so the 16-byte reads of 8 rows
                                    // (one 128-byte LDS access) fall into different banks
 
-template <bool HAS_RES, bool RELU, bool NT>
+// RB = 32-row blocks per tile: with 2 a wave runs two independent MFMA chains over the same weights (half the barriers and
+// tile edges per MFMA; 64-row tiles, 133 KB of LDS); the residual form keeps RB = 1 (its 16 extra registers per block).
+template <bool HAS_RES, bool RELU, bool NT, int RB>
 __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
                                                                int64_t ldw, const float* __restrict__ bias, const float* res,
                                                                int64_t ldr, float* C, int64_t ldc, int M, int N, int n_tiles,
                                                                int n_groups, int wg_per_group) {
-    __shared__ __attribute__((aligned(16))) float As[2][WR_BM * WR_LDA];
+    static_assert(RB == 1 || (RB == 2 && !HAS_RES), "two row blocks only without a residual");
+    constexpr int BM = WR_BM * RB;
+    __shared__ __attribute__((aligned(16))) float As[2][BM * WR_LDA];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int group = blockIdx.x % n_groups, slot = blockIdx.x / n_groups;
     const int h = lane >> 5;
@@ -47,12 +52,13 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __re
     }
     const float b = bias != nullptr ? bias[lcol] : 0.0f;
 
-    // staging: wave v brings rows 4 v .. 4 v + 3 of a tile, lane l the floats 4 l .. 4 l + 3 of each (whole rows, 1 KB per request)
-    float4 st[4];
+    // staging: wave v brings rows 4 RB v .. 4 RB v + 4 RB - 1 of a tile, lane l the floats 4 l .. 4 l + 3 of each (whole rows, 1 KB
+    // per request)
+    float4 st[4 * RB];
     auto load_tile = [&](int tile) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = min(tile * WR_BM + wave * 4 + i, M - 1);
+        for (int i = 0; i < 4 * RB; ++i) {
+            const int row = min(tile * BM + wave * 4 * RB + i, M - 1);
             st[i] = *reinterpret_cast<const float4*>(A + (int64_t)row * lda + 4 * lane);
         }
     };
@@ -60,12 +66,12 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __re
     auto write_tile = [&](int buf) {
         const bool odd = (lane & 1) != 0;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < 4 * RB; ++i) {
             const float4 v = st[i];
             const float r0 = lane_xor<1>(odd ? v.x : v.y);
             const float r1 = lane_xor<1>(odd ? v.z : v.w);
             const float4 o = odd ? make_float4(r0, r1, v.y, v.w) : make_float4(v.x, v.z, r0, r1);
-            *reinterpret_cast<float4*>(&As[buf][(wave * 4 + i) * WR_LDA + 4 * lane]) = o;
+            *reinterpret_cast<float4*>(&As[buf][(wave * 4 * RB + i) * WR_LDA + 4 * lane]) = o;
         }
     };
 
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __re
     for (; tile < n_tiles; tile += wg_per_group) {
         const int nxt = tile + wg_per_group;
         if (nxt < n_tiles) load_tile(nxt);
-        const int row0 = tile * WR_BM + 4 * h;     // accumulator register r holds row row0 + (r & 3) + 8 (r >> 2), column col
+        const int row0 = tile * BM + 4 * h;     // accumulator register r of block rb holds row row0 + 32 rb + (r & 3) + 8 (r >> 2), column col
         float rv[16];
         if (HAS_RES) {
 #pragma unroll
@@ -88,37 +94,58 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __re
                 rv[r] = res[(int64_t)row * ldr + lcol];
             }
         }
-        f32x16 acc;
+        f32x16 acc[RB];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = b;
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[rb][r] = b;
         const float* ap = &As[buf][(lane & 31) * WR_LDA + 4 * h];
-        // operands of the k-steps 4 q .. 4 q + 3 are requested two groups (eight MFMAs) ahead; the scheduling barriers keep the
-        // requests where they are written (left alone, the compiler moves every read down to just before its first use)
-        float4 a0 = *reinterpret_cast<const float4*>(ap), a1 = *reinterpret_cast<const float4*>(ap + 8), a2 = a1;
+        // operands of the k-steps 4 q .. 4 q + 3 are requested two groups ahead; the scheduling barriers keep the requests where
+        // they are written (left alone, the compiler moves every read down to just before its first use)
+        float4 a0[RB], a1[RB], a2[RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            a0[rb] = *reinterpret_cast<const float4*>(ap + rb * 32 * WR_LDA);
+            a1[rb] = *reinterpret_cast<const float4*>(ap + rb * 32 * WR_LDA + 8);
+            a2[rb] = a1[rb];
+        }
 #pragma unroll
         for (int q = 0; q < WR_K / 8; ++q) {
-            if (q + 2 < WR_K / 8) a2 = *reinterpret_cast<const float4*>(ap + (q + 2) * 8);
+            if (q + 2 < WR_K / 8) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) a2[rb] = *reinterpret_cast<const float4*>(ap + rb * 32 * WR_LDA + (q + 2) * 8);
+            }
             __builtin_amdgcn_sched_barrier(0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, w[4 * q + 0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, w[4 * q + 1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, w[4 * q + 2], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, w[4 * q + 3], acc, 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[rb].x, w[4 * q + 0], acc[rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[rb].y, w[4 * q + 1], acc[rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[rb].z, w[4 * q + 2], acc[rb], 0, 0, 0);
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) acc[rb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[rb].w, w[4 * q + 3], acc[rb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            a0 = a1;
-            a1 = a2;
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                a0[rb] = a1[rb];
+                a1[rb] = a2[rb];
+            }
         }
         // the next tile goes to LDS BEFORE this tile's results are stored: the wait for its loads (requested a whole tile ago)
         // must not have the stores in front of it, or every tile would end with a wait for their completion
         if (nxt < n_tiles) write_tile(buf ^ 1);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = row0 + (r & 3) + 8 * (r >> 2);
-            float v = acc[r];
-            if (RELU) v = v > 0.0f ? v : 0.0f;
-            if (HAS_RES) v = v + rv[r];
-            if (row < M && col_ok) {
-                if (NT) __builtin_nontemporal_store(v, &C[(int64_t)row * ldc + col]);
-                else C[(int64_t)row * ldc + col] = v;
+        for (int rb = 0; rb < RB; ++rb) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + 32 * rb + (r & 3) + 8 * (r >> 2);
+                float v = acc[rb][r];
+                if (RELU) v = v > 0.0f ? v : 0.0f;
+                if (HAS_RES) v = v + rv[r];
+                if (row < M && col_ok) {
+                    if (NT) __builtin_nontemporal_store(v, &C[(int64_t)row * ldc + col]);
+                    else C[(int64_t)row * ldc + col] = v;
+                }
             }
         }
         // a barrier over LDS only (__syncthreads() would also wait for the stores above to complete)
@@ -135,20 +162,28 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __re
 bool tst_gemm_wreg_ok(int64_t M, int64_t N, int64_t K) { return K == WR_K && N >= 1 && (N + WR_BN - 1) / WR_BN <= 256 && M >= 1; }
 
 // nontemporal: the results leave the caches as they are written (logits that another kernel reads once, later)
+static bool wreg_two_blocks() {     // TST_WREG_ROW_BLOCKS=1 in the environment (measurements): 32-row tiles for every launch
+    static const bool v = [] { const char* e = getenv("TST_WREG_ROW_BLOCKS"); return !(e != nullptr && e[0] == '1'); }();
+    return v;
+}
+
 void tst_launch_gemm_wreg(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res, int64_t ldr,
                           float* C, int64_t ldc, int64_t M, int64_t N, int act, int nontemporal, hipStream_t st) {
     const int n_groups = (int)((N + WR_BN - 1) / WR_BN);
-    const int n_tiles = (int)((M + WR_BM - 1) / WR_BM);
+    const bool nt = nontemporal && res == nullptr && act != 1;
+    const int rb = (nt && M >= 4096 && wreg_two_blocks()) ? 2 : 1;
+    const int n_tiles = (int)((M + WR_BM * rb - 1) / (WR_BM * rb));
     const int wg_per_group = n_tiles < 256 / n_groups ? n_tiles : 256 / n_groups;      // one workgroup per CU
     const dim3 grid((unsigned)(n_groups * wg_per_group));
-#define TST_WREG_LAUNCH(HR, RL, NT)                                                                                                        \
-    hipLaunchKernelGGL((gemm_f32_wreg_kernel<HR, RL, NT>), grid, dim3(512), 0, st, A, lda, Wt, ldw, bias, res, ldr, C, ldc, (int)M, (int)N, \
+#define TST_WREG_LAUNCH(HR, RL, NT, RB)                                                                                                        \
+    hipLaunchKernelGGL((gemm_f32_wreg_kernel<HR, RL, NT, RB>), grid, dim3(512), 0, st, A, lda, Wt, ldw, bias, res, ldr, C, ldc, (int)M, (int)N, \
                        n_tiles, n_groups, wg_per_group)
-    if (nontemporal && res == nullptr && act != 1) TST_WREG_LAUNCH(false, false, true);
-    else if (res != nullptr) {
-        if (act == 1) TST_WREG_LAUNCH(true, true, false); else TST_WREG_LAUNCH(true, false, false);
+    if (nt) {
+        if (rb == 2) TST_WREG_LAUNCH(false, false, true, 2); else TST_WREG_LAUNCH(false, false, true, 1);
+    } else if (res != nullptr) {
+        if (act == 1) TST_WREG_LAUNCH(true, true, false, 1); else TST_WREG_LAUNCH(true, false, false, 1);
     } else {
-        if (act == 1) TST_WREG_LAUNCH(false, true, false); else TST_WREG_LAUNCH(false, false, false);
+        if (act == 1) TST_WREG_LAUNCH(false, true, false, 1); else TST_WREG_LAUNCH(false, false, false, 1);
     }
 #undef TST_WREG_LAUNCH
 }
