@@ -64,7 +64,7 @@ print('RESULT ' + json.dumps(out))
 
 def run_child(extra_env):
     env = dict(os.environ)
-    for k in ('TST_TFM_CHAIN', 'TST_VOCAB_VARIANT', 'TST_BF16_LN_FUSE', 'TST_GEMM_WREG'):
+    for k in ('TST_TFM_CHAIN', 'TST_VOCAB_VARIANT', 'TST_BF16_LN_FUSE', 'TST_GEMM_WREG', 'TST_LN_WREG', 'TST_WREG_ROW_BLOCKS'):
         env.pop(k, None)
     env.update(extra_env)
     p = subprocess.run([sys.executable, '-c', CHILD], env=env, capture_output=True, text=True, timeout=300)
@@ -81,6 +81,7 @@ def default_result():
 
 @pytest.mark.parametrize('env', [{'TST_TFM_CHAIN': '1'}, {'TST_VOCAB_VARIANT': '4'}, {'TST_VOCAB_VARIANT': '2'},
                                  {'TST_BF16_LN_FUSE': '256'}, {'TST_TFM_CHAIN': '1', 'TST_VOCAB_VARIANT': '4'}, {'TST_GEMM_WREG': '1'}, {'TST_VOCAB_VARIANT': '3'},
-                                 {'TST_VOCAB_VARIANT': '3', 'TST_GEMM_WREG': '1'}])
+                                 {'TST_VOCAB_VARIANT': '3', 'TST_GEMM_WREG': '1'}, {'TST_LN_WREG': '1'}, {'TST_LN_WREG': '2'},
+                                 {'TST_WREG_ROW_BLOCKS': '1'}])
 def test_alternative_kernels_give_the_default_outputs(default_result, env):
     assert run_child(env) == default_result

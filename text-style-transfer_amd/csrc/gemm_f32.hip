@@ -379,6 +379,16 @@ void launch_gemm_k32(const float* A, int64_t lda, const float* Wt, int64_t ldw, 
 #undef TST_K32_LAUNCH
 }
 
+int tst_ln_wreg_mode() {
+    static const int v = [] { const char* e = getenv("TST_LN_WREG"); return (e != nullptr && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 0; }();
+    return v;
+}
+
+int64_t tst_ln_wreg_min_rows() {
+    static const int64_t v = [] { const char* e = getenv("TST_LN_WREG_MIN_ROWS"); return (e != nullptr && atoll(e) > 0) ? (int64_t)atoll(e) : (int64_t)3072; }();
+    return v;
+}
+
 bool tst_gemm_wreg_on() {
     static const bool v = [] { const char* e = getenv("TST_GEMM_WREG"); return e != nullptr && e[0] == '1'; }();
     return v;
@@ -963,6 +973,13 @@ extern "C" int tst_ln_gemm_f32(const float* x, const float* gamma, const float* 
         const hipStream_t st = (hipStream_t)stream;
         if (tiles16 <= 768) launch_skinny_ln<1>(x, K, gamma, beta, eps, Wt, ldw, bias, C, ldc, M, N, K, act, st);
         else launch_skinny_ln<2>(x, K, gamma, beta, eps, Wt, ldw, bias, C, ldc, M, N, K, act, st);
+        return tst_after_launch("tst_ln_gemm_f32");
+    }
+    // large, K = 256, only under TST_LN_WREG in the environment (1: outputs of at least 512 columns, 2: all; from
+    // TST_LN_WREG_MIN_ROWS rows, default 3072): LayerNorm inside the staging of the kernel that keeps the weights in registers.
+    // Same bits; measured equal or slower inside the decode loop than the LayerNorm launch + tile kernels, hence off.
+    if (K == 256 && tst_ln_wreg_mode() > 0 && tst_gemm_wreg_ok(M, N, K) && M >= tst_ln_wreg_min_rows() && (N >= 512 || tst_ln_wreg_mode() == 2)) {
+        tst_launch_gemm_wreg_ln(x, gamma, beta, eps, Wt, ldw, bias, C, ldc, M, N, act, (hipStream_t)stream);
         return tst_after_launch("tst_ln_gemm_f32");
     }
     const int rc2 = tst_layernorm_f32(x, gamma, beta, eps, h, M, K, stream);

@@ -14,6 +14,7 @@
 // Same arithmetic as every other fp32 product here: acc = bias[n]; for k ascending: acc = fma(A[m][k], Wt[k][n], acc),
 // then relu, then + residual.  C may alias the residual (each element is read and then written by the same lane).
 #include "tst_common.h"
+#include <math.h>
 #include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -28,12 +29,16 @@ constexpr int WR_LDA = WR_K + 4;   // floats per LDS row: consecutive rows start
 
 // RB = 32-row blocks per tile: with 2 a wave runs two independent MFMA chains over the same weights (half the barriers and
 // tile edges per MFMA; 64-row tiles, 133 KB of LDS); the residual form keeps RB = 1 (its 16 extra registers per block).
-template <bool HAS_RES, bool RELU, bool NT, int RB>
+// LN: the rows of A are normalised on their way into LDS (LayerNorm over the 256 elements of a row with gamma / beta): a wave
+// stages whole rows with lane l holding the floats 4 l .. 4 l + 3, which is the layout of layernorm_reg_kernel, so the same
+// operations in the same order give the same bits as the separate LayerNorm launch.
+template <bool HAS_RES, bool RELU, bool NT, int RB, bool LN>
 __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __restrict__ A, int64_t lda, const float* __restrict__ W,
                                                                int64_t ldw, const float* __restrict__ bias, const float* res,
                                                                int64_t ldr, float* C, int64_t ldc, int M, int N, int n_tiles,
-                                                               int n_groups, int wg_per_group) {
-    static_assert(RB == 1 || (RB == 2 && !HAS_RES), "two row blocks only without a residual");
+                                                               int n_groups, int wg_per_group, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float eps) {
+    static_assert(RB == 1 || (RB == 2 && !HAS_RES && !LN), "two row blocks only without a residual and without LayerNorm");
     constexpr int BM = WR_BM * RB;
     __shared__ __attribute__((aligned(16))) float As[2][BM * WR_LDA];
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -63,11 +68,33 @@ __global__ __launch_bounds__(512, 1) void gemm_f32_wreg_kernel(const float* __re
         }
     };
     // lanes 2 g and 2 g + 1 hold k = 8 g .. 8 g + 7 of a row; they exchange two values each and write (0, 2, 4, 6) and (1, 3, 5, 7)
+    float4 gg = make_float4(0.f, 0.f, 0.f, 0.f), bb = gg;
+    if (LN) {
+        gg = reinterpret_cast<const float4*>(gamma)[lane];
+        bb = reinterpret_cast<const float4*>(beta)[lane];
+    }
     auto write_tile = [&](int buf) {
         const bool odd = (lane & 1) != 0;
 #pragma unroll
         for (int i = 0; i < 4 * RB; ++i) {
-            const float4 v = st[i];
+            float4 v = st[i];
+            if (LN) {   // layernorm_reg_kernel<float, 1>, operation for operation
+                float p = 0.0f;
+                p = p + v.x; p = p + v.y; p = p + v.z; p = p + v.w;
+                const float mean = wave_sum_butterfly(p) / 256.0f;
+                p = 0.0f;
+                float t;
+                t = v.x - mean; p = __builtin_fmaf(t, t, p);
+                t = v.y - mean; p = __builtin_fmaf(t, t, p);
+                t = v.z - mean; p = __builtin_fmaf(t, t, p);
+                t = v.w - mean; p = __builtin_fmaf(t, t, p);
+                const float var = wave_sum_butterfly(p) / 256.0f;
+                const float rstd = 1.0f / sqrtf(var + eps);
+                v.x = __builtin_fmaf((v.x - mean) * rstd, gg.x, bb.x);
+                v.y = __builtin_fmaf((v.y - mean) * rstd, gg.y, bb.y);
+                v.z = __builtin_fmaf((v.z - mean) * rstd, gg.z, bb.z);
+                v.w = __builtin_fmaf((v.w - mean) * rstd, gg.w, bb.w);
+            }
             const float r0 = lane_xor<1>(odd ? v.x : v.y);
             const float r1 = lane_xor<1>(odd ? v.z : v.w);
             const float4 o = odd ? make_float4(r0, r1, v.y, v.w) : make_float4(v.x, v.z, r0, r1);
@@ -175,9 +202,9 @@ void tst_launch_gemm_wreg(const float* A, int64_t lda, const float* Wt, int64_t 
     const int n_tiles = (int)((M + WR_BM * rb - 1) / (WR_BM * rb));
     const int wg_per_group = n_tiles < 256 / n_groups ? n_tiles : 256 / n_groups;      // one workgroup per CU
     const dim3 grid((unsigned)(n_groups * wg_per_group));
-#define TST_WREG_LAUNCH(HR, RL, NT, RB)                                                                                                        \
-    hipLaunchKernelGGL((gemm_f32_wreg_kernel<HR, RL, NT, RB>), grid, dim3(512), 0, st, A, lda, Wt, ldw, bias, res, ldr, C, ldc, (int)M, (int)N, \
-                       n_tiles, n_groups, wg_per_group)
+#define TST_WREG_LAUNCH(HR, RL, NT, RB)                                                                                                 \
+    hipLaunchKernelGGL((gemm_f32_wreg_kernel<HR, RL, NT, RB, false>), grid, dim3(512), 0, st, A, lda, Wt, ldw, bias, res, ldr, C, ldc, \
+                       (int)M, (int)N, n_tiles, n_groups, wg_per_group, (const float*)nullptr, (const float*)nullptr, 0.0f)
     if (nt) {
         if (rb == 2) TST_WREG_LAUNCH(false, false, true, 2); else TST_WREG_LAUNCH(false, false, true, 1);
     } else if (res != nullptr) {
@@ -186,4 +213,19 @@ void tst_launch_gemm_wreg(const float* A, int64_t lda, const float* Wt, int64_t 
         if (act == 1) TST_WREG_LAUNCH(false, true, false, 1); else TST_WREG_LAUNCH(false, false, false, 1);
     }
 #undef TST_WREG_LAUNCH
+}
+
+// C = epilogue(bias + LayerNorm(x) * Wt): x [M][256] row-major and contiguous, gamma / beta [256]
+void tst_launch_gemm_wreg_ln(const float* x, const float* gamma, const float* beta, float eps, const float* Wt, int64_t ldw,
+                             const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int act, hipStream_t st) {
+    const int n_groups = (int)((N + WR_BN - 1) / WR_BN);
+    const int n_tiles = (int)((M + WR_BM - 1) / WR_BM);
+    const int wg_per_group = n_tiles < 256 / n_groups ? n_tiles : 256 / n_groups;
+    const dim3 grid((unsigned)(n_groups * wg_per_group));
+    if (act == 1)
+        hipLaunchKernelGGL((gemm_f32_wreg_kernel<false, true, false, 1, true>), grid, dim3(512), 0, st, x, (int64_t)WR_K, Wt, ldw, bias,
+                           (const float*)nullptr, (int64_t)0, C, ldc, (int)M, (int)N, n_tiles, n_groups, wg_per_group, gamma, beta, eps);
+    else
+        hipLaunchKernelGGL((gemm_f32_wreg_kernel<false, false, false, 1, true>), grid, dim3(512), 0, st, x, (int64_t)WR_K, Wt, ldw, bias,
+                           (const float*)nullptr, (int64_t)0, C, ldc, (int)M, (int)N, n_tiles, n_groups, wg_per_group, gamma, beta, eps);
 }

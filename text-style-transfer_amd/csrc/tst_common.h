@@ -31,6 +31,9 @@ bool tst_gemm_wreg_ok(int64_t M, int64_t N, int64_t K);
 void tst_launch_gemm_wreg(const float* A, int64_t lda, const float* Wt, int64_t ldw, const float* bias, const float* res, int64_t ldr,
                           float* C, int64_t ldc, int64_t M, int64_t N, int act, int nontemporal, hipStream_t st);
 
+void tst_launch_gemm_wreg_ln(const float* x, const float* gamma, const float* beta, float eps, const float* Wt, int64_t ldw,
+                             const float* bias, float* C, int64_t ldc, int64_t M, int64_t N, int act, hipStream_t st);
+
 // attn_mfma.hip: the matrix-core cross-attention of beam groups (used by tst_attn_cross_group_f32)
 int tst_cross_mfma_ok(int64_t S, int64_t dh, int64_t group);
 int tst_launch_cross_mfma(const float* kv, const int32_t* kvrow, const float* q, const uint8_t* mask, const int32_t* sent, int64_t S,
