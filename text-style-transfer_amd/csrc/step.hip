@@ -202,6 +202,8 @@ extern "C" int tst_tfm_step_run(const tst_tfm_step* m, const int32_t* tok, const
             TST_TRY(tst_ln_vocab_argmax_f32(m->x, m->ln_g, m->ln_b, m->eps, (const float*)m->wout, m->ld_wout, m->bout, m->argmax_keys, R, m->V,
                                             d, stream));
         else if (wreg_vocab) {
+            TST_REQUIRE(m->ld_wout >= m->V && m->ld_logits >= m->V && tst_aligned16(m->h), TST_ERR_ARG,
+                        "tst_tfm_step_run: ld_wout and ld_logits must be at least V, h 16-byte aligned");
             tst_launch_gemm_wreg((const float*)m->h, d, (const float*)m->wout, m->ld_wout, m->bout, nullptr, 0, (float*)m->logits, m->ld_logits, R,
                                  m->V, 0, 1, (hipStream_t)stream);
             TST_TRY(tst_after_launch("tst_tfm_step_run: vocabulary projection"));
