@@ -369,3 +369,22 @@ def test_whole_path_under_inference_mode_and_no_grad(T, mode):
     assert inside == plain
     assert plain[0][0] != plain[1][0]                       # the edit of the encoder outputs changed the decode
     assert all(len(s) == 1 for s in plain[0][1])            # and the edited bias ended every sentence at once
+
+
+@pytest.mark.parametrize('B,V', [(1024, 300), (1030, 256), (4095, 70), (4096, 513), (4100, 300), (4163, 1000)])
+def test_projection_with_weights_in_registers_at_its_tile_and_size_boundaries(T, B, V):
+    """The vocabulary projection of d_model-256 steps runs the weights-in-registers kernel from 1024 rows (32-row tiles) and its
+    64-row form from 4096: row counts at and around both switches, with a last tile that is partial, and vocabulary sizes that
+    are no multiple of the 256-column group (a partial last group, a single partial group): the logits of EVERY row of the
+    first two steps equal the canonical oracle's bit for bit."""
+    tmodel, model, vocab, encs, mask = mt_case(T, V, B, 3, 0.0, 11)
+    st = T.InferenceState({'model': model.decoder, 'inputs': torch.from_numpy(encs).cuda(), 'enc_mask': torch.from_numpy(mask).cuda(),
+                           'vocab': vocab, 'max_len': 2})
+    out = [s.cpu().tolist() for s in st.inference(keep_logits=2)]
+    sess = C.CanonTransformerDecoder(tmodel.decoder, 2).session(encs, mask, 1, 2)
+    want, logits, rows = C.greedy_decode(sess, B, 2, 2, 3, 2)
+    assert out == want
+    for i in range(len(logits)):
+        lg, sent, _ = st.loop.kept[i]
+        assert np.array_equal(sent.cpu().numpy(), rows[i])
+        assert np.array_equal(lg.cpu().numpy()[:, :V], logits[i]), (B, V, i)
